@@ -1,0 +1,156 @@
+/*
+ * psa.h -- C ABI of the MI355X (gfx950) alignment library, libpsa_hip.so.
+ *
+ * This is the drop-in boundary for ONE path of agarfel/Parallel-Sequence-Alignment: the
+ * three-table dynamic-programming fill and alignment reconstruction of `simple.cpp`.  The
+ * reference has no FFI; its in-process boundary is `result run(int p, str A, str B)`
+ * (simple.cpp:261) called once by `main` (simple.cpp:311).  Every entry point below cites the
+ * reference code it replaces.  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Conventions
+ *   - return 0 on success, a negative PSA_E* code on failure; psa_last_error() gives the text
+ *     (thread-local).  The library never falls back to a CPU path: with no usable GPU every
+ *     compute entry point fails with PSA_E_NO_DEVICE.
+ *   - residues are raw bytes; only byte equality is used (simple.cpp:13-16), so any injective
+ *     byte->uint8 encoding gives identical results and the identity is used.
+ *   - alignment columns are pairs (ai[k], bj[k]) of 0-based indices into A and B, -1 = gap
+ *     (simple.h:24), already including the prefix fix-up of simple.cpp:279-290.
+ *   - host output arrays are allocated by the library and released with psa_free().
+ *   - one call at a time per stripe object; different stripe objects are independent.
+ */
+#ifndef PSA_H
+#define PSA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSA_OK 0
+#define PSA_E_ARG (-1)        /* bad argument */
+#define PSA_E_NO_DEVICE (-2)  /* no usable HIP device: the product path has no CPU fallback */
+#define PSA_E_HIP (-3)        /* a HIP runtime call failed */
+#define PSA_E_NOMEM (-4)      /* host or device allocation failed */
+#define PSA_E_KERNEL (-5)     /* a kernel reported a stalled hand-off (bounded spin expired) */
+#define PSA_E_STATE (-6)      /* calls made in the wrong order */
+
+#define PSA_F_TRACEBACK 1u    /* keep packed winner codes in HBM so an alignment can be rebuilt */
+
+const char* psa_last_error(void);
+const char* psa_version(void);
+int psa_device_count(void);
+/* Select the HIP device used by subsequent calls of this thread (hipSetDevice). */
+int psa_set_device(int device);
+void psa_free(void* p);
+
+/* ---- whole-pair entry points: replace run() (simple.cpp:261-294) ---------------------- */
+
+/*
+ * Align A (n bytes) against B (m bytes).  `p` is the reference's third argument: the number
+ * of column stripes B is cut into (block = m/p, the last stripe takes the remainder,
+ * simple.cpp:90-99).  Here the stripes run as a pipeline on the current GPU; as in the
+ * reference the result does not depend on p.  p < 1 is an error (the reference divides by
+ * zero, simple.cpp:92).
+ * Outputs: *score_out = result.score; (*ai_out, *bj_out, *len_out) = result.al.data.
+ */
+int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
+              int32_t* score_out, int32_t** ai_out, int32_t** bj_out, int64_t* len_out);
+
+/* Score only: the fill of simple.cpp:122-240 and the final pick of simple.cpp:244-256 with no
+ * traceback storage.  triple_out (may be NULL) receives T1,T2,T3 at (n, m). */
+int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
+              int32_t* score_out, int32_t triple_out[3]);
+
+/*
+ * Many independent pairs, score only, one GPU, no communication (BASELINE config 5).
+ * seqs/offsets: sequence s is seqs[offsets[s] .. offsets[s+1]); pairs[2k], pairs[2k+1] are
+ * the sequence numbers of pair k's A and B.  scores_out[k] = what run() would return as
+ * result.score for that pair.  No counterpart in the reference beyond calling run() in a loop.
+ */
+int psa_score_batch(const uint8_t* seqs, const int64_t* offsets, int64_t nseqs,
+                    const int32_t* pairs, int64_t npairs, int32_t* scores_out);
+
+/* The five stdout lines of the reference (simple.cpp:312-313, output_alignement 43-70) for a
+ * result; returned buffer is released with psa_free(), *out_len is its length in bytes. */
+char* psa_format_result(int32_t score, const uint8_t* a, const uint8_t* b, const int32_t* ai,
+                        const int32_t* bj, int64_t len, int64_t* out_len);
+
+/* Host-side prefix fix-up of simple.cpp:279-290 + find_last (simple.cpp:24-41), applied in
+ * place to a traceback given in REVERSE order (as psa_stripe_traceback emits it).  On return
+ * the arrays hold the final alignment in forward order; cap must be >= len + n + m. */
+int psa_finish_alignment(int32_t* ai, int32_t* bj, int64_t len, int64_t cap, int64_t* len_out);
+
+/* ---- column-stripe objects: the reference's per-thread stripe, one per GPU -------------
+ *
+ * A psa_stripe is one thread's share in solve_subproblem_parallel (simple.cpp:87-259): all
+ * rows of A against columns c0+1..c1 of B, resident on one GPU.  Rows are filled in chunks,
+ * top to bottom.  For each chunk the caller supplies the left boundary -- T1,T2,T3 of column
+ * c0 for the chunk's rows, what the reference passes through sharingT (simple.cpp:143-149)
+ * -- and receives the right boundary (simple.cpp:223-229) to hand to the next stripe.
+ * Between GPUs those buffers travel by RCCL send/recv; on one GPU they are passed directly.
+ */
+typedef struct psa_stripe psa_stripe;
+
+/* a, b are HOST pointers to the full sequences; columns (c0, c1] of B are kept. 0<=c0<=c1<=m. */
+int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8_t* b,
+                      int64_t m, int64_t c0, int64_t c1, uint32_t flags);
+void psa_stripe_destroy(psa_stripe* s);
+
+/* Same stripe, new sequences of the same lengths already RESIDENT in device memory
+ * (a_dev: n bytes, b_dev: the stripe's c1-c0 bytes).  Device-to-device copy on `stream`. */
+int psa_stripe_set_sequences_dev(psa_stripe* s, const uint8_t* a_dev, const uint8_t* b_dev,
+                                 void* stream);
+
+/*
+ * Fill rows r0+1..r1.  Chunks must be given in order: the first call has r0 = 0, each later
+ * call has r0 = the previous r1; r0 must be a multiple of 64 (one wavefront owns 64 rows).
+ * left_dev : DEVICE pointer to 3*(r1-r0) int32, [k*(r1-r0) + y] = T_{k+1}(r0+1+y, c0), or
+ *            NULL when c0 == 0 (the head stripe computes its own column 0,
+ *            simple.cpp:124-133).
+ * right_dev: DEVICE pointer to 3*(r1-r0) int32 receiving the same layout at column c1, or
+ *            NULL when nobody consumes it.
+ * stream   : hipStream_t (NULL = the default stream).  The call is asynchronous.
+ */
+int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev,
+                         int32_t* right_dev, void* stream);
+
+/* T1,T2,T3 at (n, c1) after the last chunk (synchronises `stream`).  For the last stripe
+ * pick() of these is the score (simple.cpp:246-256). */
+int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]);
+
+/*
+ * Walk the alignment back through this stripe (needs PSA_F_TRACEBACK).  State (i, j, k):
+ * cell (i, j) of table k; the first call starts at (n, m, k*) with k* the
+ * winning table of the final pick.  The walk proceeds while the predecessor cell lies in
+ * this stripe's columns (or on the matrix boundary when c0 == 0) and stops either at the
+ * matrix boundary (i == 0 or j == 0) or when the predecessor belongs to the stripe on the
+ * left; the state then returned is handed to that stripe.  Columns are APPENDED in walk
+ * order (i.e. reversed) to ai/bj (HOST arrays of capacity cap) starting at *len_io.
+ */
+int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai,
+                         int32_t* bj, int64_t cap, int64_t* len_io, void* stream);
+
+/* Duration in milliseconds of the most recent psa_stripe_fill_rows / psa_stripe_traceback
+ * kernel of this stripe, measured with HIP events on the launch stream (synchronises). */
+int psa_stripe_last_fill_ms(psa_stripe* s, float* ms_out);
+int psa_stripe_last_traceback_ms(psa_stripe* s, float* ms_out);
+/* Bytes of packed winner codes this stripe writes per full fill (the traceback stream). */
+int64_t psa_stripe_code_bytes(const psa_stripe* s);
+
+/* ---- helpers shared with the command-line front end ------------------------------------ */
+
+/* The reference's FASTA reader (read_fasta.cpp:8-23).  Returns a buffer to release with
+ * psa_free() (never NULL on success; NULL + *len_out = 0 when the file cannot be opened,
+ * after printing the reference's message on stderr). */
+uint8_t* psa_read_fasta(const char* path, int64_t* len_out);
+
+/* Synthetic iid-uniform protein over ACDEFGHIKLMNPQRSTVWY: out[k] = alphabet[g() % 20] with
+ * std::mt19937_64 g(seed).  Host-side. */
+void psa_synth_protein(uint64_t seed, int64_t n, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,228 @@
+"""ctypes binding of include/psa.h (the reference-side binding a maintainer would add)."""
+import ctypes as C
+import os
+from collections import namedtuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+lib_path = os.path.join(_HERE, "lib", "libpsa_hip.so")
+
+PSA_F_TRACEBACK = 1
+
+_lib = None
+
+
+class PsaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("psa error %d: %s" % (code, msg))
+        self.code = code
+
+
+#: mirror of the reference's ``result`` (simple.h:54-69): score + alignment columns
+Result = namedtuple("Result", ["score", "ai", "bj"])
+
+_i64, _i32, _u8p = C.c_int64, C.c_int32, C.POINTER(C.c_uint8)
+_i32p, _i64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+
+_SIGNATURES = {
+    "psa_last_error": (C.c_char_p, []),
+    "psa_version": (C.c_char_p, []),
+    "psa_device_count": (C.c_int, []),
+    "psa_set_device": (C.c_int, [C.c_int]),
+    "psa_free": (None, [C.c_void_p]),
+    "psa_align": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, C.c_int, _i32p, C.POINTER(C.c_void_p),
+                            C.POINTER(C.c_void_p), _i64p]),
+    "psa_score": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, C.c_int, _i32p, _i32p]),
+    "psa_score_batch": (C.c_int, [C.c_void_p, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p]),
+    "psa_format_result": (C.c_void_p, [_i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64, _i64p]),
+    "psa_finish_alignment": (C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64p]),
+    "psa_stripe_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _i64, C.c_void_p, _i64, _i64, _i64,
+                                    C.c_uint32]),
+    "psa_stripe_destroy": (None, [C.c_void_p]),
+    "psa_stripe_set_sequences_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psa_stripe_fill_rows": (C.c_int, [C.c_void_p, _i64, _i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psa_stripe_final": (C.c_int, [C.c_void_p, C.c_void_p, _i32p]),
+    "psa_stripe_traceback": (C.c_int, [C.c_void_p, _i64p, _i64p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
+                                       _i64, _i64p, C.c_void_p]),
+    "psa_stripe_last_fill_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "psa_stripe_last_traceback_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "psa_stripe_code_bytes": (_i64, [C.c_void_p]),
+    "psa_read_fasta": (C.c_void_p, [C.c_char_p, _i64p]),
+    "psa_synth_protein": (None, [C.c_uint64, _i64, C.c_void_p]),
+}
+
+EXPORTS = tuple(sorted(_SIGNATURES))
+
+
+def lib():
+    """Load libpsa_hip.so (built in-tree by `make` / __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(lib_path):
+            raise PsaError(-2, "%s is missing: run `make` (there is no CPU fallback)" % lib_path)
+        L = C.CDLL(lib_path)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise PsaError(rc, lib().psa_last_error().decode("utf-8", "replace"))
+
+
+def _seq(x):
+    """bytes / str / uint8 array -> contiguous uint8 numpy array (identity byte encoding)."""
+    if isinstance(x, str):
+        x = x.encode("latin-1")
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        return np.frombuffer(bytes(x), dtype=np.uint8)
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def _ptr(arr):
+    return arr.ctypes.data_as(C.c_void_p) if arr.size else None
+
+
+def device_count():
+    return lib().psa_device_count()
+
+
+def set_device(dev):
+    _check(lib().psa_set_device(int(dev)))
+
+
+def pick(t1, t2, t3):
+    """The reference's three-way tie-break (simple.cpp:162/166/170): returns (table, value)."""
+    if t1 >= t2 and t1 >= t3:
+        return 1, t1
+    if t2 >= t3:
+        return 2, t2
+    return 3, t3
+
+
+def align(a, b, p=1):
+    """run(p, A, B) of the reference (simple.cpp:261): returns Result(score, ai, bj)."""
+    a, b = _seq(a), _seq(b)
+    score = _i32()
+    ai, bj, n = C.c_void_p(), C.c_void_p(), _i64()
+    _check(lib().psa_align(_ptr(a), a.size, _ptr(b), b.size, int(p), C.byref(score), C.byref(ai), C.byref(bj),
+                           C.byref(n)))
+    try:
+        if n.value:
+            xa = np.ctypeslib.as_array(C.cast(ai, _i32p), shape=(n.value,)).copy()
+            xb = np.ctypeslib.as_array(C.cast(bj, _i32p), shape=(n.value,)).copy()
+        else:
+            xa = np.zeros(0, np.int32)
+            xb = np.zeros(0, np.int32)
+    finally:
+        lib().psa_free(ai)
+        lib().psa_free(bj)
+    return Result(score.value, xa, xb)
+
+
+run = lambda p, a, b: align(a, b, p)  # noqa: E731  (argument order of the reference)
+
+
+def score(a, b, p=1, triple=False):
+    a, b = _seq(a), _seq(b)
+    s = _i32()
+    t = (_i32 * 3)()
+    _check(lib().psa_score(_ptr(a), a.size, _ptr(b), b.size, int(p), C.byref(s), t))
+    return (s.value, tuple(t)) if triple else s.value
+
+
+def format_result(res, a, b):
+    """The reference's stdout for a result (simple.cpp:312-313, 43-70), as bytes."""
+    a, b = _seq(a), _seq(b)
+    ai = np.ascontiguousarray(res.ai, np.int32)
+    bj = np.ascontiguousarray(res.bj, np.int32)
+    n = _i64()
+    p = lib().psa_format_result(res.score, _ptr(a), _ptr(b), _ptr(ai), _ptr(bj), ai.size, C.byref(n))
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        lib().psa_free(p)
+
+
+def finish_alignment(ai_rev, bj_rev, n, m):
+    """Prefix fix-up of simple.cpp:279-290 on a reversed traceback; returns forward (ai, bj)."""
+    ln = len(ai_rev)
+    cap = ln + n + m + 2
+    ai = np.zeros(cap, np.int32)
+    bj = np.zeros(cap, np.int32)
+    ai[:ln] = ai_rev
+    bj[:ln] = bj_rev
+    out = _i64()
+    _check(lib().psa_finish_alignment(_ptr(ai), _ptr(bj), ln, cap, C.byref(out)))
+    return ai[:out.value].copy(), bj[:out.value].copy()
+
+
+def read_fasta(path):
+    n = _i64()
+    p = lib().psa_read_fasta(os.fsencode(path), C.byref(n))
+    if not p:
+        return b""
+    try:
+        return C.string_at(p, n.value)
+    finally:
+        lib().psa_free(p)
+
+
+def synth_protein(seed, n):
+    out = np.zeros(int(n), np.uint8)
+    lib().psa_synth_protein(C.c_uint64(seed), int(n), _ptr(out))
+    return out
+
+
+class Stripe:
+    """One column stripe of B on the current GPU (a thread's share in simple.cpp:87-259)."""
+
+    def __init__(self, a, b, c0, c1, traceback=True):
+        self.a, self.b = _seq(a), _seq(b)
+        self.n, self.m, self.c0, self.c1 = self.a.size, self.b.size, int(c0), int(c1)
+        self._h = C.c_void_p()
+        _check(lib().psa_stripe_create(C.byref(self._h), _ptr(self.a), self.n, _ptr(self.b), self.m, self.c0,
+                                       self.c1, PSA_F_TRACEBACK if traceback else 0))
+
+    def close(self):
+        if self._h:
+            lib().psa_stripe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_sequences_dev(self, a_ptr, b_ptr, stream=0):
+        _check(lib().psa_stripe_set_sequences_dev(self._h, a_ptr, b_ptr, stream))
+
+    def fill_rows(self, r0, r1, left_ptr=None, right_ptr=None, stream=0):
+        """left_ptr / right_ptr: device addresses (int) of int32[3][r1-r0] or None."""
+        _check(lib().psa_stripe_fill_rows(self._h, r0, r1, left_ptr, right_ptr, stream))
+
+    def final(self, stream=0):
+        t = (_i32 * 3)()
+        _check(lib().psa_stripe_final(self._h, stream, t))
+        return tuple(t)
+
+    def traceback(self, i, j, k, ai, bj, length, stream=0):
+        """Append reversed columns to numpy int32 arrays ai/bj from `length`; returns (i, j, k, length)."""
+        ci, cj, ck, cl = _i64(i), _i64(j), C.c_int(k), _i64(length)
+        _check(lib().psa_stripe_traceback(self._h, C.byref(ci), C.byref(cj), C.byref(ck), _ptr(ai), _ptr(bj),
+                                          ai.size, C.byref(cl), stream))
+        return ci.value, cj.value, ck.value, cl.value
+
+    def last_fill_ms(self):
+        v = C.c_float()
+        _check(lib().psa_stripe_last_fill_ms(self._h, C.byref(v)))
+        return v.value
+
+    def last_traceback_ms(self):
+        v = C.c_float()
+        _check(lib().psa_stripe_last_traceback_ms(self._h, C.byref(v)))
+        return v.value
+
+    def code_bytes(self):
+        return lib().psa_stripe_code_bytes(self._h)

@@ -1,0 +1,455 @@
+// psa_hip.hip -- C ABI (include/psa.h) over the gfx950 kernels.  No CPU fallback: every
+// compute entry point needs a HIP device and fails with PSA_E_NO_DEVICE otherwise.
+#include "../../include/psa.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "psa_kernels.hip.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? PSA_E_NOMEM : PSA_E_HIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(e_));                                       \
+    } while (0)
+
+int need_device() {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt < 1)
+        return fail(PSA_E_NO_DEVICE, "no HIP device available (%s); this library has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return PSA_OK;
+}
+
+// simple.cpp:162/166/170: table 1 if t1>=t2 && t1>=t3, else 2 if t2>=t3, else 3.
+int pick3(const int32_t t[3], int32_t* v) {
+    if (t[0] >= t[1] && t[0] >= t[2]) { *v = t[0]; return 1; }
+    if (t[1] >= t[2]) { *v = t[1]; return 2; }
+    *v = t[2];
+    return 3;
+}
+
+constexpr size_t kCtrlBytes = 256;
+
+}  // namespace
+
+struct psa_stripe {
+    int64_t n = 0, m = 0, c0 = 0, c1 = 0;
+    int W = 0, Q = 0, Wpad = 0;
+    uint32_t flags = 0;
+    uint8_t* a_dev = nullptr;
+    uint8_t* b_dev = nullptr;
+    psa::u64* ring = nullptr;
+    uint32_t* codes = nullptr;
+    size_t code_bytes = 0;
+    int32_t* small = nullptr;    // corner A[3] (pad 4), corner B[3] (pad 4), final[3] (pad 4)
+    unsigned* ctrl = nullptr;    // [0] ticket, [1] abort
+    int32_t* tb_ai = nullptr;
+    int32_t* tb_bj = nullptr;
+    int64_t tb_cap = 0;
+    int64_t* tb_state = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t next_r0 = 0;
+    int corner_cur = 0;
+    bool fill_timed = false, tb_timed = false;
+};
+
+extern "C" {
+
+const char* psa_last_error(void) { return g_err.c_str(); }
+const char* psa_version(void) { return "psa-hip 0.1 (gfx950)"; }
+
+int psa_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int psa_set_device(int device) {
+    if (int rc = need_device()) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return PSA_OK;
+}
+
+void psa_free(void* p) { free(p); }
+
+void psa_stripe_destroy(psa_stripe* s) {
+    if (!s) return;
+    hipFree(s->a_dev); hipFree(s->b_dev); hipFree(s->ring); hipFree(s->codes);
+    hipFree(s->small); hipFree(s->ctrl); hipFree(s->tb_ai); hipFree(s->tb_bj); hipFree(s->tb_state);
+    for (auto& e : s->ev) if (e) hipEventDestroy(e);
+    delete s;
+}
+
+int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8_t* b, int64_t m,
+                      int64_t c0, int64_t c1, uint32_t flags) {
+    if (!out) return fail(PSA_E_ARG, "psa_stripe_create: out is null");
+    *out = nullptr;
+    if (n < 1 || m < 1 || c0 < 0 || c1 <= c0 || c1 > m || !a || !b)
+        return fail(PSA_E_ARG, "psa_stripe_create: need n>=1, m>=1, 0<=c0<c1<=m (n=%lld m=%lld c0=%lld c1=%lld)",
+                    (long long)n, (long long)m, (long long)c0, (long long)c1);
+    if (n > (1LL << 27) || m > (1LL << 27)) return fail(PSA_E_ARG, "sequence longer than 2^27 is not supported");
+    if (int rc = need_device()) return rc;
+    psa_stripe* s = new psa_stripe();
+    s->n = n; s->m = m; s->c0 = c0; s->c1 = c1; s->flags = flags;
+    s->W = (int)(c1 - c0);
+    s->Q = (s->W + 63 + 63) / 64;
+    s->Wpad = ((s->W + 63) / 64) * 64;
+    const int64_t strips = (n + 63) / 64;
+#define CREATE_TRY(expr)                                                          \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            psa_stripe_destroy(s);                                                \
+            return fail(e_ == hipErrorOutOfMemory ? PSA_E_NOMEM : PSA_E_HIP,      \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));           \
+        }                                                                         \
+    } while (0)
+    CREATE_TRY(hipMalloc(&s->a_dev, (size_t)n));
+    CREATE_TRY(hipMalloc(&s->b_dev, (size_t)s->W));
+    CREATE_TRY(hipMemcpy(s->a_dev, a, (size_t)n, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(s->b_dev, b + c0, (size_t)s->W, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(&s->ring, sizeof(psa::u64) * 2 * (size_t)s->Wpad));
+    CREATE_TRY(hipMalloc(&s->small, 64));
+    CREATE_TRY(hipMalloc(&s->ctrl, kCtrlBytes));
+    if (flags & PSA_F_TRACEBACK) {
+        s->code_bytes = (size_t)strips * (size_t)s->Q * 3 * 64 * 4 * sizeof(uint32_t);
+        CREATE_TRY(hipMalloc(&s->codes, s->code_bytes));
+        s->tb_cap = n + s->W + 2;
+        CREATE_TRY(hipMalloc(&s->tb_ai, sizeof(int32_t) * (size_t)s->tb_cap));
+        CREATE_TRY(hipMalloc(&s->tb_bj, sizeof(int32_t) * (size_t)s->tb_cap));
+        CREATE_TRY(hipMalloc(&s->tb_state, sizeof(int64_t) * 8));
+    }
+    for (auto& e : s->ev) CREATE_TRY(hipEventCreate(&e));
+#undef CREATE_TRY
+    *out = s;
+    return PSA_OK;
+}
+
+int psa_stripe_set_sequences_dev(psa_stripe* s, const uint8_t* a_dev, const uint8_t* b_dev, void* stream) {
+    if (!s || !a_dev || !b_dev) return fail(PSA_E_ARG, "psa_stripe_set_sequences_dev: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(s->a_dev, a_dev, (size_t)s->n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->b_dev, b_dev, (size_t)s->W, hipMemcpyDeviceToDevice, st));
+    return PSA_OK;
+}
+
+int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev,
+                         void* stream) {
+    if (!s) return fail(PSA_E_ARG, "psa_stripe_fill_rows: null stripe");
+    if (r0 == 0) s->next_r0 = 0;  // a new pass over the same stripe
+    if (r0 != s->next_r0) return fail(PSA_E_STATE, "psa_stripe_fill_rows: chunks out of order (r0=%lld, expected %lld)",
+                                      (long long)r0, (long long)s->next_r0);
+    if ((r0 & 63) || r1 <= r0 || r1 > s->n)
+        return fail(PSA_E_ARG, "psa_stripe_fill_rows: need r0 %% 64 == 0 and r0 < r1 <= n (r0=%lld r1=%lld n=%lld)",
+                    (long long)r0, (long long)r1, (long long)s->n);
+    if ((s->c0 == 0) != (left_dev == nullptr))
+        return fail(PSA_E_ARG, "psa_stripe_fill_rows: left boundary must be given exactly when c0 > 0");
+    hipStream_t st = (hipStream_t)stream;
+    if (r0 == 0) {
+        HIP_TRY(hipMemsetAsync(s->ring, 0, sizeof(psa::u64) * 2 * (size_t)s->Wpad, st));
+        s->corner_cur = 0;
+    }
+    HIP_TRY(hipMemsetAsync(s->ctrl, 0, kCtrlBytes, st));
+    psa::FillArgs fa;
+    fa.a = s->a_dev; fa.b = s->b_dev; fa.n = s->n; fa.r0 = r0; fa.r1 = r1; fa.c0 = s->c0;
+    fa.W = s->W; fa.Q = s->Q; fa.Wpad = s->Wpad;
+    fa.left = left_dev;
+    fa.corner = s->small + 4 * s->corner_cur;
+    fa.corner_next = s->small + 4 * (s->corner_cur ^ 1);
+    fa.right = right_dev;
+    fa.final_triple = s->small + 8;
+    fa.ring = s->ring;
+    fa.codes = s->codes;
+    fa.ticket = s->ctrl;
+    fa.abort_flag = s->ctrl + 1;
+    const unsigned strips = (unsigned)((r1 - r0 + 63) / 64);
+    HIP_TRY(hipEventRecord(s->ev[0], st));
+    if (s->codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fa);
+    else hipLaunchKernelGGL(psa::fill_strips_v1<false>, dim3(strips), dim3(64), 0, st, fa);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev[1], st));
+    s->fill_timed = true;
+    s->corner_cur ^= 1;
+    s->next_r0 = r1;
+    return PSA_OK;
+}
+
+static int check_abort(psa_stripe* s, hipStream_t st) {
+    unsigned ctrl[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(ctrl, s->ctrl, sizeof ctrl, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctrl[1]) return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired");
+    return PSA_OK;
+}
+
+int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]) {
+    if (!s || !triple_out) return fail(PSA_E_ARG, "psa_stripe_final: null argument");
+    if (s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_final: rows filled up to %lld of %lld",
+                                        (long long)s->next_r0, (long long)s->n);
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = check_abort(s, st)) return rc;
+    HIP_TRY(hipMemcpy(triple_out, s->small + 8, 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return PSA_OK;
+}
+
+int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai, int32_t* bj,
+                         int64_t cap, int64_t* len_io, void* stream) {
+    if (!s || !i_io || !j_io || !k_io || !ai || !bj || !len_io) return fail(PSA_E_ARG, "psa_stripe_traceback: null argument");
+    if (!s->codes) return fail(PSA_E_STATE, "psa_stripe_traceback: stripe was created without PSA_F_TRACEBACK");
+    if (s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_traceback: fill is not complete");
+    if (*k_io < 1 || *k_io > 3 || *i_io < 0 || *i_io > s->n || *j_io < 0 || *j_io > s->c1 + 1)
+        return fail(PSA_E_ARG, "psa_stripe_traceback: bad state (%lld,%lld,%d)", (long long)*i_io, (long long)*j_io, *k_io);
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = check_abort(s, st)) return rc;
+    int64_t state[8] = {*i_io, *j_io, *k_io, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(s->tb_state, state, sizeof state, hipMemcpyHostToDevice, st));
+    psa::TraceArgs ta;
+    ta.codes = s->codes; ta.c0 = s->c0; ta.W = s->W; ta.Q = s->Q; ta.cap = s->tb_cap;
+    ta.out_ai = s->tb_ai; ta.out_bj = s->tb_bj; ta.state = s->tb_state;
+    HIP_TRY(hipEventRecord(s->ev[2], st));
+    hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev[3], st));
+    s->tb_timed = true;
+    HIP_TRY(hipMemcpyAsync(state, s->tb_state, sizeof state, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (state[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow");
+    const int64_t got = state[4];
+    if (*len_io + got > cap) return fail(PSA_E_ARG, "psa_stripe_traceback: output capacity %lld too small", (long long)cap);
+    if (got) {
+        HIP_TRY(hipMemcpy(ai + *len_io, s->tb_ai, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(bj + *len_io, s->tb_bj, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost));
+    }
+    *len_io += got;
+    *i_io = state[0]; *j_io = state[1]; *k_io = (int)state[2];
+    if (!state[3] && s->c0 == 0) return fail(PSA_E_KERNEL, "traceback: head stripe stopped before the matrix boundary");
+    return PSA_OK;
+}
+
+int psa_stripe_last_fill_ms(psa_stripe* s, float* ms_out) {
+    if (!s || !ms_out || !s->fill_timed) return fail(PSA_E_STATE, "no fill has been timed");
+    HIP_TRY(hipEventSynchronize(s->ev[1]));
+    HIP_TRY(hipEventElapsedTime(ms_out, s->ev[0], s->ev[1]));
+    return PSA_OK;
+}
+
+int psa_stripe_last_traceback_ms(psa_stripe* s, float* ms_out) {
+    if (!s || !ms_out || !s->tb_timed) return fail(PSA_E_STATE, "no traceback has been timed");
+    HIP_TRY(hipEventSynchronize(s->ev[3]));
+    HIP_TRY(hipEventElapsedTime(ms_out, s->ev[2], s->ev[3]));
+    return PSA_OK;
+}
+
+int64_t psa_stripe_code_bytes(const psa_stripe* s) { return s ? (int64_t)s->code_bytes : 0; }
+
+// simple.cpp:279-290 with find_last (simple.cpp:24-41).
+int psa_finish_alignment(int32_t* ai, int32_t* bj, int64_t len, int64_t cap, int64_t* len_out) {
+    if (!ai || !bj || !len_out || len < 0) return fail(PSA_E_ARG, "psa_finish_alignment: bad argument");
+    int64_t fi = 0, fj = 0;  // std::pair value-initialises to 0 when nothing is found
+    for (int64_t t = len - 1; t >= 0; --t) if (ai[t] != -1) { fi = ai[t]; break; }
+    for (int64_t t = len - 1; t >= 0; --t) if (bj[t] != -1) { fj = bj[t]; break; }
+    if (len + fi + fj > cap) return fail(PSA_E_ARG, "psa_finish_alignment: capacity too small");
+    for (int64_t x = fi; x > 0; --x) { ai[len] = (int32_t)(x - 1); bj[len] = -1; ++len; }
+    for (int64_t x = fj; x > 0; --x) { ai[len] = -1; bj[len] = (int32_t)(x - 1); ++len; }
+    std::reverse(ai, ai + len);
+    std::reverse(bj, bj + len);
+    *len_out = len;
+    return PSA_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct StripeSet {
+    std::vector<psa_stripe*> st;
+    std::vector<int32_t*> edge;  // device boundary buffers between consecutive stripes
+    ~StripeSet() {
+        for (auto* s : st) psa_stripe_destroy(s);
+        for (auto* e : edge) hipFree(e);
+    }
+};
+
+int64_t chunk_rows_default() {
+    if (const char* e = getenv("PSA_CHUNK_ROWS")) {
+        long long v = atoll(e);
+        if (v >= 64) return (v / 64) * 64;
+    }
+    return 8192;
+}
+
+// Column stripes exactly as simple.cpp:90-99 cuts them; zero-width stripes (p > m) own no cell.
+int run_stripes(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, uint32_t flags,
+                StripeSet& set, int32_t triple[3]) {
+    const int64_t block = m / p;
+    for (int id = 0; id < p; ++id) {
+        const int64_t c0 = (int64_t)id * block;
+        const int64_t c1 = (id == p - 1) ? m : c0 + block;
+        if (c1 == c0) continue;
+        psa_stripe* s = nullptr;
+        if (int rc = psa_stripe_create(&s, a, n, b, m, c0, c1, flags)) return rc;
+        set.st.push_back(s);
+    }
+    const size_t ns = set.st.size();
+    const int64_t chunk = ns > 1 ? std::min<int64_t>(chunk_rows_default(), ((n + 63) / 64) * 64) : n;
+    for (size_t g = 0; g + 1 < ns; ++g) {
+        int32_t* e = nullptr;
+        HIP_TRY(hipMalloc(&e, sizeof(int32_t) * 3 * (size_t)chunk));
+        set.edge.push_back(e);
+    }
+    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+        const int64_t r1 = std::min(n, r0 + chunk);
+        for (size_t g = 0; g < ns; ++g) {
+            const int32_t* left = g ? set.edge[g - 1] : nullptr;
+            int32_t* right = (g + 1 < ns) ? set.edge[g] : nullptr;
+            if (int rc = psa_stripe_fill_rows(set.st[g], r0, r1, left, right, nullptr)) return rc;
+        }
+    }
+    return psa_stripe_final(set.st.back(), nullptr, triple);
+}
+
+}  // namespace
+
+extern "C" {
+
+int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, int32_t* score_out,
+              int32_t triple_out[3]) {
+    if (!score_out || n < 0 || m < 0 || (n && !a) || (m && !b)) return fail(PSA_E_ARG, "psa_score: bad argument");
+    if (p < 1) return fail(PSA_E_ARG, "p must be >= 1 (the reference divides by p, simple.cpp:92)");
+    if (int rc = need_device()) return rc;
+    int32_t t[3];
+    if (n == 0) { t[0] = -1; t[1] = 0; t[2] = (int32_t)-(2 + m); }       // loop of simple.cpp:122 never runs
+    else if (m == 0) { t[0] = -1; t[1] = (int32_t)-(2 + n); t[2] = -1; } // only column 0 exists (simple.cpp:124-133)
+    else {
+        StripeSet set;
+        if (int rc = run_stripes(a, n, b, m, p, 0, set, t)) return rc;
+    }
+    pick3(t, score_out);
+    if (triple_out) memcpy(triple_out, t, sizeof t);
+    return PSA_OK;
+}
+
+int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, int32_t* score_out,
+              int32_t** ai_out, int32_t** bj_out, int64_t* len_out) {
+    if (!score_out || !ai_out || !bj_out || !len_out || n < 0 || m < 0 || (n && !a) || (m && !b))
+        return fail(PSA_E_ARG, "psa_align: bad argument");
+    if (p < 1) return fail(PSA_E_ARG, "p must be >= 1 (the reference divides by p, simple.cpp:92)");
+    if (int rc = need_device()) return rc;
+    *ai_out = *bj_out = nullptr;
+    *len_out = 0;
+    const int64_t cap = 2 * (n + m) + 2;
+    int32_t* ai = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+    int32_t* bj = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+    if (!ai || !bj) { free(ai); free(bj); return fail(PSA_E_NOMEM, "psa_align: host allocation failed"); }
+    int32_t t[3];
+    int64_t len = 0;
+    int rc = PSA_OK;
+    if (n == 0) { t[0] = -1; t[1] = 0; t[2] = (int32_t)-(2 + m); }
+    else if (m == 0) { t[0] = -1; t[1] = (int32_t)-(2 + n); t[2] = -1; }
+    else {
+        StripeSet set;
+        rc = run_stripes(a, n, b, m, p, PSA_F_TRACEBACK, set, t);
+        if (rc == PSA_OK) {
+            int32_t v;
+            int64_t i = n, j = m;
+            int k = pick3(t, &v);
+            for (size_t g = set.st.size(); g-- > 0 && rc == PSA_OK;) {
+                rc = psa_stripe_traceback(set.st[g], &i, &j, &k, ai, bj, cap, &len, nullptr);
+                if (i == 0 || j == 0) break;
+            }
+        }
+    }
+    if (rc == PSA_OK) rc = psa_finish_alignment(ai, bj, len, cap, &len);
+    if (rc != PSA_OK) { free(ai); free(bj); return rc; }
+    pick3(t, score_out);
+    *ai_out = ai; *bj_out = bj; *len_out = len;
+    return PSA_OK;
+}
+
+int psa_score_batch(const uint8_t* seqs, const int64_t* offsets, int64_t nseqs, const int32_t* pairs,
+                    int64_t npairs, int32_t* scores_out) {
+    (void)seqs; (void)offsets; (void)nseqs; (void)pairs; (void)npairs; (void)scores_out;
+    return fail(PSA_E_STATE, "psa_score_batch: not built yet");
+}
+
+// simple.cpp:312 + output_alignement (simple.cpp:43-70); both Length lines print al_A's size.
+char* psa_format_result(int32_t score, const uint8_t* a, const uint8_t* b, const int32_t* ai, const int32_t* bj,
+                        int64_t len, int64_t* out_len) {
+    std::string out = "Score: " + std::to_string(score) + "\n";
+    out += "Length Sequence A : " + std::to_string(len) + "\n";
+    out += "Length Sequence B : " + std::to_string(len) + "\n";
+    std::string ra((size_t)len, '-'), rb((size_t)len, '-');
+    for (int64_t k = 0; k < len; ++k) {
+        if (ai[k] != -1) ra[(size_t)k] = (char)a[ai[k]];
+        if (bj[k] != -1) rb[(size_t)k] = (char)b[bj[k]];
+    }
+    out += "Sequence A : " + ra + "\nSequence B : " + rb + "\n";
+    char* buf = (char*)malloc(out.size() + 1);
+    if (!buf) return nullptr;
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    if (out_len) *out_len = (int64_t)out.size();
+    return buf;
+}
+
+// read_fasta.cpp:8-23: keep every non-empty line that does not start with '>', verbatim.
+uint8_t* psa_read_fasta(const char* path, int64_t* len_out) {
+    if (len_out) *len_out = 0;
+    FILE* f = path ? fopen(path, "rb") : nullptr;
+    if (!f) {
+        fprintf(stderr, "Error opening file: %s\n", path ? path : "(null)");
+        return nullptr;
+    }
+    std::string seq, line;
+    int ch;
+    bool any = false;
+    auto flush = [&]() {
+        if (!line.empty() && line[0] != '>') seq += line;
+        line.clear();
+    };
+    while ((ch = fgetc(f)) != EOF) {
+        any = true;
+        if (ch == '\n') flush(); else line.push_back((char)ch);
+    }
+    if (any) flush();
+    fclose(f);
+    uint8_t* buf = (uint8_t*)malloc(seq.size() + 1);
+    if (!buf) return nullptr;
+    memcpy(buf, seq.data(), seq.size());
+    if (len_out) *len_out = (int64_t)seq.size();
+    return buf;
+}
+
+void psa_synth_protein(uint64_t seed, int64_t n, uint8_t* out) {
+    static const char alphabet[] = "ACDEFGHIKLMNPQRSTVWY";
+    std::mt19937_64 g(seed);
+    for (int64_t k = 0; k < n; ++k) out[k] = (uint8_t)alphabet[g() % 20];
+}
+
+}  // extern "C"

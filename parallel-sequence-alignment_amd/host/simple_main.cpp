@@ -1,0 +1,42 @@
+// simple_main.cpp -- drop-in command line: ./simple <A.fasta> <B.fasta> <p>
+// Same contract as the reference's main (simple.cpp:297-313): inputs are read from
+// "sequences/<name>" relative to the working directory, p is parsed with std::stoi, the five
+// result lines go to stdout, exit status 0 even when a file is missing (the reader then yields
+// an empty sequence).  The alignment itself runs on the GPU through the C ABI of include/psa.h;
+// there is no CPU path, so without a usable device the program reports the error and exits 3.
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <string>
+
+#include "../../include/psa.h"
+
+int main(int argc, char* argv[]) {
+    if (argc != 4) {
+        std::cerr << "Usage: " << argv[0] << " <sequence1.fasta> <sequence2.fasta> <p>\n";
+        return 1;
+    }
+    const std::string folder = "sequences/";
+    const std::string file_a = folder + argv[1];
+    const std::string file_b = folder + argv[2];
+    const int p = std::stoi(argv[3]);  // non-numeric input aborts, as in the reference
+
+    int64_t n = 0, m = 0;
+    uint8_t* a = psa_read_fasta(file_a.c_str(), &n);
+    uint8_t* b = psa_read_fasta(file_b.c_str(), &m);
+
+    int32_t score = 0;
+    int32_t *ai = nullptr, *bj = nullptr;
+    int64_t len = 0;
+    const int rc = psa_align(a, n, b, m, p, &score, &ai, &bj, &len);
+    if (rc != PSA_OK) {
+        std::cerr << "simple: " << psa_last_error() << " (code " << rc << ")\n";
+        return 3;
+    }
+    int64_t out_len = 0;
+    char* text = psa_format_result(score, a, b, ai, bj, len, &out_len);
+    fwrite(text, 1, (size_t)out_len, stdout);
+    fflush(stdout);
+    psa_free(text); psa_free(ai); psa_free(bj); psa_free(a); psa_free(b);
+    return 0;
+}

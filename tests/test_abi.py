@@ -1,0 +1,75 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/psa.h declares, and its
+host-only helpers (FASTA reader, formatter, prefix fix-up, generator) match the reference."""
+import base64
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import psa_amd
+from make_golden_shim import MT19937_64
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "psa.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(psa_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = psa_amd.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    from importlib import import_module
+    binding = import_module("parallel-sequence-alignment_amd.binding")
+    assert declared == set(binding.EXPORTS)
+
+
+def test_no_cpu_fallback_without_gpu():
+    if psa_amd.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(psa_amd.PsaError) as e:
+        psa_amd.align(b"ACD", b"ACD", 1)
+    assert e.value.code == -2
+
+
+def test_fasta_reader_matches_reference_behaviour(tmp_path):
+    for c in O.load_golden("ref_format_cases.json"):
+        if "argv" in c:
+            continue
+        for key, name in (("a_file_b64", c["a"]), ("b_file_b64", c["b"])):
+            path = tmp_path / name
+            if c[key] is None:
+                assert psa_amd.read_fasta(str(tmp_path / "does_not_exist.fasta")) == b""
+                continue
+            path.write_bytes(base64.b64decode(c[key]))
+            assert psa_amd.read_fasta(str(path)) == O.read_fasta(str(path))
+
+
+def test_format_and_finish_match_oracle():
+    # host-only pieces (simple.cpp:43-70, 279-290) checked against the pinned oracle
+    for c in O.load_golden("ref_fuzz.json")[:60]:
+        sc, ai, bj = O.align(c["a_seq"], c["b_seq"])
+        res = psa_amd.Result(sc, ai, bj)
+        assert psa_amd.format_result(res, c["a_seq"], c["b_seq"]) == O.b64d(c["stdout_b64"])
+    rev_ai = np.array([-1, 4, 3, -1], np.int32)
+    rev_bj = np.array([7, 6, -1, 5], np.int32)
+    ai, bj = psa_amd.finish_alignment(rev_ai, rev_bj, 10, 10)
+    # first A index 3 -> rows 0..2 prepended; first B index 5 -> columns 0..4 prepended first
+    assert list(bj[:5]) == [0, 1, 2, 3, 4] and list(ai[:5]) == [-1] * 5
+    assert list(ai[5:8]) == [0, 1, 2] and list(bj[5:8]) == [-1] * 3
+    assert list(ai[8:]) == [-1, 3, 4, -1] and list(bj[8:]) == [5, -1, 6, 7]
+
+
+def test_synth_generator_is_mt19937_64():
+    g = MT19937_64(0xA0000000 + 16)
+    alpha = "ACDEFGHIKLMNPQRSTVWY"
+    want = "".join(alpha[g() % 20] for _ in range(1000)).encode()
+    assert bytes(psa_amd.synth_protein(0xA0000000 + 16, 1000)) == want
+
+
+def test_argument_errors():
+    with pytest.raises(psa_amd.PsaError):
+        psa_amd.align(b"AC", b"AC", 0)

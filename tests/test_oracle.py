@@ -1,0 +1,110 @@
+"""CPU suite: the oracle (oracle/psa_oracle.c) against the goldens produced by the real reference.
+
+These pin the restatement: every fixture in tests/golden/ref_*.json is stdout of the compiled
+reference (tests/golden/make_golden.py).  No GPU needed.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def test_fuzz_goldens_single_thread():
+    cases = O.load_golden("ref_fuzz.json")
+    assert len(cases) == 300
+    for c in cases:
+        assert O.stdout_for(c["a_seq"], c["b_seq"]) == O.b64d(c["stdout_b64"])
+
+
+def test_fuzz_goldens_striped_threads():
+    # the reference's own decomposition (p stripes); output must not depend on p
+    cases = O.load_golden("ref_fuzz.json")
+    for k, c in enumerate(cases[::3]):
+        p = [1, 2, 3, 5, 8, 13][k % 6]
+        assert O.stdout_for(c["a_seq"], c["b_seq"], p) == O.b64d(c["stdout_b64"])
+
+
+def test_fasta_pair_goldens(golden_dir):
+    for c in O.load_golden("ref_fasta_pairs.json"):
+        a = O.read_fasta(os.path.join(golden_dir, "sequences", c["a"]))
+        b = O.read_fasta(os.path.join(golden_dir, "sequences", c["b"]))
+        assert O.stdout_for(a, b, 4) == O.b64d(c["stdout_b64"]), (c["a"], c["b"])
+
+
+def test_random_protein_goldens(golden_dir):
+    for c in O.load_golden("ref_random.json"):
+        a = O.read_fasta(os.path.join(golden_dir, "sequences", c["a"]))
+        b = O.read_fasta(os.path.join(golden_dir, "sequences", c["b"]))
+        assert O.stdout_for(a, b) == O.b64d(c["stdout_b64"])
+        assert O.stdout_for(a, b, 8) == O.b64d(c["stdout_b64"])
+
+
+def test_format_cases(tmp_path):
+    import base64
+    for c in O.load_golden("ref_format_cases.json"):
+        if "argv" in c:
+            continue
+        seqs = []
+        for key, name in (("a_file_b64", c["a"]), ("b_file_b64", c["b"])):
+            path = tmp_path / name
+            if c[key] is None:
+                if path.exists():
+                    path.unlink()
+            else:
+                path.write_bytes(base64.b64decode(c[key]))
+            seqs.append(O.read_fasta(str(path)))
+        assert O.stdout_for(seqs[0], seqs[1]) == O.b64d(c["stdout_b64"]), (c["a"], c["b"])
+        assert c["rc"] == 0
+
+
+def test_known_survey_values(golden_dir):
+    # SURVEY 8c table
+    rd = lambda n: O.read_fasta(os.path.join(golden_dir, "sequences", n))
+    out = O.stdout_for(rd("insulin_homo.fasta"), rd("insulin_bovin.fasta"))
+    assert hashlib.md5(out).hexdigest() == "7bc3956188dcaa02e82f5213b1ed5e8c"
+    assert out.startswith(b"Score: 169\nLength Sequence A : 110\n")
+    out = O.stdout_for(rd("Q16739_homo.fasta"), rd("A0A2I3N2W7_baboon.fasta"))
+    assert hashlib.md5(out).hexdigest() == "c8a552d9d71d534f4ea143a53413fa90"
+
+
+def test_score_only_matches_align():
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        n, m = rng.integers(0, 90, 2)
+        a = rng.integers(65, 65 + 3, n).astype(np.uint8)
+        b = rng.integers(65, 65 + 3, m).astype(np.uint8)
+        s, _, _ = O.align(a, b)
+        assert O.score(a, b) == s
+        assert O.score(a, b, 3) == s
+
+
+def test_block_composes():
+    # filling the matrix as a 2x2 grid of blocks with explicit boundaries equals the whole
+    rng = np.random.default_rng(11)
+    n, m = 150, 170
+    a = rng.integers(65, 69, n).astype(np.uint8)
+    b = rng.integers(65, 69, m).astype(np.uint8)
+    top = np.array([[O.boundary(0, j)[k] for j in range(m + 1)] for k in range(3)], np.int32)
+    left = np.array([[O.boundary(i, 0)[k] for i in range(n + 1)] for k in range(3)], np.int32)
+    bot_full, right_full = O.block(a, b, 0, n, 0, m, top, left)
+    r, c = 64, 100
+    b00, r00 = O.block(a, b, 0, r, 0, c, top[:, :c + 1], left[:, :r + 1])
+    b01, r01 = O.block(a, b, 0, r, c, m, top[:, c:], r00)
+    b10, r10 = O.block(a, b, r, n, 0, c, b00, left[:, r:])
+    b11, r11 = O.block(a, b, r, n, c, m, b01, r10)
+    assert np.array_equal(b11, bot_full[:, c:])
+    assert np.array_equal(r11, right_full[:, r:])
+    t = bot_full[:, m]
+    assert O.score(a, b) == max(t)
+
+
+@pytest.mark.slow
+def test_titin_restatement_md5(golden_dir):
+    # restatement-only golden (the reference cannot run this pair: ~58 GB, ~19 h); SURVEY 8c
+    rd = lambda n: O.read_fasta(os.path.join(golden_dir, "sequences", n))
+    out = O.stdout_for(rd("titin_homo(50).fasta"), rd("titin_mus.fasta"), 8)
+    assert hashlib.md5(out).hexdigest() == "65af487c90fa2638ce05f3a6badbaaea"
+    assert out.startswith(b"Score: 62103\nLength Sequence A : 35289\n")
