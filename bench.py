@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- GCUPS of the alignment hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete alignment of the workload pair: DP fill with packed winner codes
+written to HBM, final pick, traceback walk, prefix fix-up (what run() does in simple.cpp:261-294).
+Inputs are resident in HBM before the timed region.  N = 1: the synthetic 2^16 x 2^16 protein
+pair of BASELINE config 4 on one GPU.  N > 1 (launched by torch.distributed.run, one rank per
+GPU): the same pair cut into N column stripes, stripe g on GPU g, boundary columns streamed
+g -> g+1 with RCCL send/recv in row chunks (strong scaling).  Rank 0 prints ONE JSON line.
+
+Extra keys beside the contract: roofline (int32 VALU), cpu_baseline (the oracle's
+multi-threaded port timed on host cores, rank 0, N = 1 only), and secondary measurements
+(score-only fill, titin pair) under "extra".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+VALU_PEAK_TOPS = 39.3216      # 256 CU x 64 int32 lanes/clk x 2.4 GHz (tools/valu_peak measures 38.8)
+OPS_PER_CELL_CODES = 25       # algorithmic int32 VALU ops per cell with winner codes
+OPS_PER_CELL_SCORE = 10       # score only
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
+    ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(a, b, log2s=15):
+    """Oracle's striped multi-thread port (kind "port") on a bounded prefix sample of the workload."""
+    import oracle_lib as O
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    s = min(len(a), len(b), 1 << log2s)
+    t0 = time.perf_counter()
+    sc, ai, bj = O.align(a[:s], b[:s], cores)
+    dt = time.perf_counter() - t0
+    return {"value": s * s / dt / 1e9, "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": "prefix %dx%d of the workload pair, fill + codes + traceback, %d threads (oracle/psa_oracle.c "
+                      "psa_oracle_align_mt), %.2f s" % (s, s, cores, dt),
+            "score": int(sc)}
+
+
+def single_gpu(args):
+    import torch
+    import psa_amd
+    torch.cuda.set_device(0)
+    psa_amd.set_device(0)
+    k = args.log2n
+    n = m = 1 << k
+    a = psa_amd.synth_protein(0xA0000000 + k, n)
+    b = psa_amd.synth_protein(0xB0000000 + k, m)
+    a_dev = torch.from_numpy(a).cuda()
+    b_dev = torch.from_numpy(b).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    st = psa_amd.Stripe(a, b, 0, m, traceback=True)
+    import numpy as np
+    cap = 2 * (n + m) + 2
+    ai = np.zeros(cap, np.int32)
+    bj = np.zeros(cap, np.int32)
+
+    def step():
+        st.set_sequences_dev(a_dev.data_ptr(), b_dev.data_ptr(), stream)
+        st.fill_rows(0, n, None, None, stream)
+        t = st.final(stream)
+        kk, sc = psa_amd.pick(*t)
+        _, _, _, ln = st.traceback(n, m, kk, ai, bj, 0, stream)
+        fa, fb = psa_amd.finish_alignment(ai[:ln], bj[:ln], n, m)
+        return sc, len(fa)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    fill_ms, tb_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sc, ln = step()
+        fill_ms.append(st.last_fill_ms())
+        tb_ms.append(st.last_traceback_ms())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cells = float(n) * m
+    ms_step = dt / args.steps * 1e3
+    fill = sum(fill_ms) / len(fill_ms)
+    achieved = cells * OPS_PER_CELL_CODES / (fill * 1e-3) / 1e12
+    code_bytes = st.code_bytes()
+    out = {
+        "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of a 2^%d x 2^%d pair" % (k, k),
+        "value": cells / (dt / args.steps) / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": "synthetic iid 20-letter protein pair 2^%d x 2^%d (mt19937_64 seeds 0xA/0xB0000000+%d), "
+                               "fill with packed winner codes in HBM + traceback walk + prefix fix-up" % (k, k, k),
+                   "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1},
+        "roofline": {"bound": "valu", "kernel": "fill_strips (with winner codes)", "achieved": achieved,
+                     "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
+                     "ops_per_cell": OPS_PER_CELL_CODES, "kernel_ms": fill, "fill_gcups": cells / (fill * 1e-3) / 1e9,
+                     "structural_ceiling": min(1.0, cells / ((n + m) * 65536.0)),
+                     "traffic": None,
+                     "code_stream": {"bytes": code_bytes, "GBps": code_bytes / (fill * 1e-3) / 1e9,
+                                     "frac_of_hbm_peak": code_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        "traceback_ms": sum(tb_ms) / len(tb_ms),
+    }
+    st.close()
+    extra = {}
+    if not args.no_extra:
+        # score-only fill of the same pair
+        so = psa_amd.Stripe(a, b, 0, m, traceback=False)
+        for _ in range(2):
+            so.fill_rows(0, n, None, None, stream)
+        ts = []
+        for _ in range(3):
+            so.fill_rows(0, n, None, None, stream)
+            ts.append(so.last_fill_ms())
+        t = so.final(stream)
+        so.close()
+        ms = sum(ts) / len(ts)
+        extra["score_only_2p%d" % k] = {"gcups": cells / (ms * 1e-3) / 1e9, "kernel_ms": ms, "score": int(max(t)),
+                                        "valu_frac": cells * OPS_PER_CELL_SCORE / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
+        # titin pair (BASELINE config 3), full alignment
+        seqdir = os.path.join(ROOT, "tests", "golden", "sequences")
+        ta = psa_amd.read_fasta(os.path.join(seqdir, "titin_homo(50).fasta"))
+        tb = psa_amd.read_fasta(os.path.join(seqdir, "titin_mus.fasta"))
+        psa_amd.align(ta, tb, 1)
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            res = psa_amd.align(ta, tb, 1)
+        dtt = (time.perf_counter() - t0) / reps
+        extra["titin_pair"] = {"gcups_end_to_end_host_buffers": len(ta) * len(tb) / dtt / 1e9, "ms": dtt * 1e3,
+                               "score": int(res.score), "alignment_len": int(len(res.ai)),
+                               "note": "psa_align from host buffers: includes allocation, H2D and D2H"}
+    out["extra"] = extra
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a, b)
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from bench_multi import multi_gpu
+        out = multi_gpu(args)
+    else:
+        out = single_gpu(args)
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

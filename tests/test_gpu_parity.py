@@ -1,0 +1,120 @@
+"""GPU suite: the HIP path (through the C ABI) against the oracle and the reference goldens.
+Bar: bit-exact scores, alignment columns and stdout bytes."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import psa_amd
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def gpu_stdout(a, b, p=1):
+    res = psa_amd.align(a, b, p)
+    return psa_amd.format_result(res, a, b)
+
+
+def test_wave_shift_smoke():
+    # smallest end-to-end case first: a fault here names the kernel, not a big input
+    res = psa_amd.align(b"H", b"LC", 1)
+    sc, ai, bj = O.align(b"H", b"LC")
+    assert res.score == sc and list(res.ai) == list(ai) and list(res.bj) == list(bj)
+
+
+def test_fuzz_goldens():
+    cases = O.load_golden("ref_fuzz.json")
+    for k, c in enumerate(cases):
+        p = c["p"] if k % 2 else 1
+        assert gpu_stdout(c["a_seq"], c["b_seq"], p) == O.b64d(c["stdout_b64"]), k
+
+
+def test_fasta_pair_goldens(golden_dir):
+    for c in O.load_golden("ref_fasta_pairs.json"):
+        a = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", c["a"]))
+        b = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", c["b"]))
+        assert gpu_stdout(a, b, c["p"]) == O.b64d(c["stdout_b64"]), (c["a"], c["b"])
+
+
+def test_random_protein_goldens(golden_dir):
+    for c in O.load_golden("ref_random.json"):
+        a = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", c["a"]))
+        b = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", c["b"]))
+        for p in (1, 3):
+            assert gpu_stdout(a, b, p) == O.b64d(c["stdout_b64"])
+
+
+def test_degenerate_inputs():
+    for a, b in ((b"", b""), (b"", b"ACD"), (b"ACD", b""), (b"A", b""), (b"A", b"A"), (b"A", b"C")):
+        for p in (1, 4):
+            res = psa_amd.align(a, b, p)
+            sc, ai, bj = O.align(a, b)
+            assert (res.score, list(res.ai), list(res.bj)) == (sc, list(ai), list(bj)), (a, b, p)
+            assert psa_amd.score(a, b, p) == sc
+
+
+@pytest.mark.parametrize("alpha", [2, 4, 20])
+def test_random_vs_oracle_tile_edges(alpha):
+    rng = np.random.default_rng(100 + alpha)
+    sizes = [(1, 1), (1, 200), (200, 1), (63, 63), (64, 64), (65, 65), (64, 1), (65, 127), (128, 129),
+             (191, 65), (257, 300), (300, 257), (511, 513), (1000, 37), (37, 1000), (777, 1234)]
+    for n, m in sizes:
+        a = rng.integers(65, 65 + alpha, n).astype(np.uint8)
+        b = rng.integers(65, 65 + alpha, m).astype(np.uint8)
+        sc, ai, bj = O.align(a, b)
+        for p in (1, 2, 5):
+            res = psa_amd.align(a, b, p)
+            assert res.score == sc, (n, m, p)
+            assert np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (n, m, p)
+        assert psa_amd.score(a, b, 1) == sc
+
+
+def test_row_chunks_and_stripes(monkeypatch):
+    # several row chunks per stripe (chunk = 128 rows) and several stripes
+    monkeypatch.setenv("PSA_CHUNK_ROWS", "128")
+    rng = np.random.default_rng(5)
+    for n, m, p in ((700, 650, 3), (129, 900, 7), (1024, 64, 2), (1500, 1500, 4)):
+        a = rng.integers(65, 68, n).astype(np.uint8)
+        b = np.where(rng.random(m) < 0.7, np.resize(a, m), rng.integers(65, 68, m)).astype(np.uint8)
+        sc, ai, bj = O.align(a, b)
+        res = psa_amd.align(a, b, p)
+        assert res.score == sc
+        assert np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (n, m, p)
+        assert psa_amd.score(a, b, p) == sc
+
+
+def test_titin_full_traceback(golden_dir):
+    # BASELINE config 3 on one GPU; golden is restatement-only (reference cannot run it), SURVEY 8c
+    a = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "titin_homo(50).fasta"))
+    b = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "titin_mus.fasta"))
+    out = gpu_stdout(a, b, 1)
+    assert out.startswith(b"Score: 62103\nLength Sequence A : 35289\n")
+    assert hashlib.md5(out).hexdigest() == "65af487c90fa2638ce05f3a6badbaaea"
+
+
+def test_large_score_only_property():
+    # 2^14 random pair: score equals the oracle's rolling-row score (seconds on CPU);
+    # split-independence: p = 1 and p = 4 agree
+    a = psa_amd.synth_protein(0xA0000000 + 14, 1 << 14)
+    b = psa_amd.synth_protein(0xB0000000 + 14, 1 << 14)
+    want = O.score(a, b, 8)
+    assert psa_amd.score(a, b, 1) == want
+    assert psa_amd.score(a, b, 4) == want
+
+
+def test_cli_byte_exact(golden_dir):
+    exe = os.path.join(ROOT, "simple")
+    assert os.path.exists(exe), "run `make` first"
+    for c in O.load_golden("ref_fasta_pairs.json")[:6]:
+        r = subprocess.run([exe, c["a"], c["b"], str(c["p"])], cwd=golden_dir, capture_output=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == O.b64d(c["stdout_b64"])
+    r = subprocess.run([exe, "nope.fasta", "insulin_homo.fasta", "2"], cwd=golden_dir, capture_output=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith(b"Score: 0\nLength Sequence A : 0\n")
+    assert b"Error opening file: sequences/nope.fasta" in r.stderr
+    r = subprocess.run([exe, "only_one_arg"], cwd=golden_dir, capture_output=True, timeout=120)
+    assert r.returncode == 1 and b"Usage:" in r.stderr and r.stdout == b""
