@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "psa_kernels.hip.h"
+#include "psa_fill_v2.hip.h"
 
 namespace {
 
@@ -76,8 +76,45 @@ struct psa_stripe {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t next_r0 = 0;
     int corner_cur = 0;
+    // v2 kernel: symbol ids of A and the per-symbol substitution table of this stripe's B
+    uint8_t* a_ids = nullptr;
+    uint8_t* alpha = nullptr;    // present[256] (u32) | meta[4] (u32) | map[256] | inv[32]
+    uint32_t* eqtab = nullptr;
+    int tab_pitch = 0;
+    unsigned nsym = 0;
+    bool use_v2 = false;
     bool fill_timed = false, tb_timed = false;
 };
+
+namespace {
+
+constexpr size_t kAlphaBytes = 256 * 4 + 16 + 256 + 32;
+
+// FASTA-to-device encoding for the v2 kernel: symbol ids of A, substitution table of B.
+int rebuild_tables(psa_stripe* s, hipStream_t st) {
+    unsigned* present = (unsigned*)s->alpha;
+    unsigned* meta = present + 256;
+    uint8_t* map = (uint8_t*)(meta + 4);
+    uint8_t* inv = map + 256;
+    HIP_TRY(hipMemsetAsync(s->alpha, 0, kAlphaBytes, st));
+    const int blocks = (int)std::min<int64_t>(1024, (s->n + 255) / 256);
+    hipLaunchKernelGGL(psa::alphabet_presence, dim3(blocks), dim3(256), 0, st, s->a_dev, s->n, present);
+    hipLaunchKernelGGL(psa::alphabet_compact, dim3(1), dim3(64), 0, st, present, meta, map, inv);
+    hipLaunchKernelGGL(psa::encode_rows, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, st, s->a_dev, s->n, map,
+                       s->a_ids);
+    hipLaunchKernelGGL(psa::build_eqtab, dim3((unsigned)((s->tab_pitch + 255) / 256), psa::kMaxSym), dim3(256), 0, st,
+                       s->b_dev, s->W, meta, inv, s->eqtab, s->tab_pitch);
+    HIP_TRY(hipGetLastError());
+    unsigned k = 0;
+    HIP_TRY(hipMemcpyAsync(&k, meta, sizeof k, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    s->nsym = k;
+    const char* force = getenv("PSA_FILL_KERNEL");
+    s->use_v2 = k <= (unsigned)psa::kMaxSym && !(force && !strcmp(force, "v1"));
+    return PSA_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -101,6 +138,7 @@ void psa_free(void* p) { free(p); }
 void psa_stripe_destroy(psa_stripe* s) {
     if (!s) return;
     hipFree(s->a_dev); hipFree(s->b_dev); hipFree(s->ring); hipFree(s->codes);
+    hipFree(s->a_ids); hipFree(s->alpha); hipFree(s->eqtab);
     hipFree(s->small); hipFree(s->ctrl); hipFree(s->tb_ai); hipFree(s->tb_bj); hipFree(s->tb_state);
     for (auto& e : s->ev) if (e) hipEventDestroy(e);
     delete s;
@@ -146,7 +184,12 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
         CREATE_TRY(hipMalloc(&s->tb_state, sizeof(int64_t) * 8));
     }
     for (auto& e : s->ev) CREATE_TRY(hipEventCreate(&e));
+    s->tab_pitch = psa::kTabPad + (64 * s->Q + 64) / 8 + 8;
+    CREATE_TRY(hipMalloc(&s->a_ids, (size_t)n));
+    CREATE_TRY(hipMalloc(&s->alpha, kAlphaBytes));
+    CREATE_TRY(hipMalloc(&s->eqtab, sizeof(uint32_t) * (size_t)psa::kMaxSym * (size_t)s->tab_pitch));
 #undef CREATE_TRY
+    if (int rc = rebuild_tables(s, nullptr)) { psa_stripe_destroy(s); return rc; }
     *out = s;
     return PSA_OK;
 }
@@ -156,7 +199,7 @@ int psa_stripe_set_sequences_dev(psa_stripe* s, const uint8_t* a_dev, const uint
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(s->a_dev, a_dev, (size_t)s->n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->b_dev, b_dev, (size_t)s->W, hipMemcpyDeviceToDevice, st));
-    return PSA_OK;
+    return rebuild_tables(s, st);
 }
 
 int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev,
@@ -188,13 +231,40 @@ int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* l
     fa.codes = s->codes;
     fa.ticket = s->ctrl;
     fa.abort_flag = s->ctrl + 1;
+    fa.prof = nullptr;
+    const char* prof_path = getenv("PSA_PROFILE_STRIPS");
+    psa::u64* prof_dev = nullptr;
+    const unsigned nstrips_prof = (unsigned)((r1 - r0 + 63) / 64);
+    if (prof_path && s->use_v2) {
+        HIP_TRY(hipMalloc(&prof_dev, sizeof(psa::u64) * 4 * nstrips_prof));
+        HIP_TRY(hipMemsetAsync(prof_dev, 0, sizeof(psa::u64) * 4 * nstrips_prof, st));
+        fa.prof = prof_dev;
+    }
     const unsigned strips = (unsigned)((r1 - r0 + 63) / 64);
     HIP_TRY(hipEventRecord(s->ev[0], st));
-    if (s->codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fa);
+    if (s->use_v2) {
+        psa::FillArgs2 fb;
+        fb.base = fa; fb.a_ids = s->a_ids; fb.eqtab = s->eqtab; fb.tab_pitch = s->tab_pitch;
+        const unsigned wgs = (strips + psa::kNW - 1) / psa::kNW;
+        if (s->codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(wgs), dim3(psa::kNW * 64), 0, st, fb);
+        else hipLaunchKernelGGL(psa::fill_strips_v2<false>, dim3(wgs), dim3(psa::kNW * 64), 0, st, fb);
+    } else if (s->codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fa);
     else hipLaunchKernelGGL(psa::fill_strips_v1<false>, dim3(strips), dim3(64), 0, st, fa);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], st));
     s->fill_timed = true;
+    if (prof_dev) {  // diagnostic only: dump per-strip start/end ticks and placement
+        std::vector<psa::u64> h(4 * (size_t)nstrips_prof);
+        HIP_TRY(hipMemcpy(h.data(), prof_dev, sizeof(psa::u64) * h.size(), hipMemcpyDeviceToHost));
+        hipFree(prof_dev);
+        if (FILE* f = fopen(prof_path, "w")) {
+            fprintf(f, "strip,start,end,xcc,hwid\n");
+            for (unsigned k = 0; k < nstrips_prof; ++k)
+                fprintf(f, "%u,%llu,%llu,%llu,%llu\n", k, h[4 * k] - h[0], h[4 * k + 1] - h[0], h[4 * k + 2] >> 32,
+                        h[4 * k + 2] & 0xffffffffu);
+            fclose(f);
+        }
+    }
     s->corner_cur ^= 1;
     s->next_r0 = r1;
     return PSA_OK;

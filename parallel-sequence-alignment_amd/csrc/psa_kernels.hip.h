@@ -31,6 +31,7 @@ struct FillArgs {
     uint32_t* codes;         // packed winner bits or null
     unsigned* ticket;        // strip ticket counter (zeroed per launch)
     unsigned* abort_flag;    // set when a bounded spin expires
+    u64* prof;               // optional [strips][4]: start, end (100 MHz ticks), placement; null = off
 };
 
 __device__ __forceinline__ u64 load_granule(const u64* p) {
