@@ -6,7 +6,7 @@ from collections import namedtuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-lib_path = os.path.join(_HERE, "lib", "libpsa_hip.so")
+lib_path = os.environ.get("PSA_LIB_PATH") or os.path.join(_HERE, "lib", "libpsa_hip.so")
 
 PSA_F_TRACEBACK = 1
 

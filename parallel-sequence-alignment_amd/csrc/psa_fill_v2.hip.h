@@ -79,6 +79,7 @@ struct __attribute__((aligned(16))) FillLds {
     int2 ring[kNW][kRing];       // ring[w]: input of wave w; slot s = (D of column s-65, V of column s-64)
     int2 stage[kNW][32];         // staging of a wave's last row on its way to HBM granules
     int dummy[kNW][64 + 48];     // where lanes other than 63 drop their publish writes
+    int dummy2[kNW][64];         // where lanes that own no counter drop their counter posts
     int prod[kNW];               // steps completed by the producer of ring[w]
     int cons[kNW];               // ring[w] slots below this number have been read
 };
@@ -113,14 +114,23 @@ struct StripState {
     int H;        // H' of this row (x2 of the next column)
     int V;        // V' of this row at its current column (x3 of the row below)
     unsigned aD, aH, aV;
+    int r1, r2, r3;  // x1, x2, x3 of this row at the stripe's last column (captured in the tail)
 };
+
+// How a block treats lanes that are outside the stripe:
+//   kFast    every lane is inside (64 <= t0, t0 + 16 <= W - 1): no predication at all
+//   kHead    t < 64 and W >= 64: lane l enters at step l, commits are predicated on lane <= t
+//   kTail    lanes leave on the right: nothing they compute is read again, so no predication;
+//            each lane captures its values at column W-1 (right boundary / final triple)
+//   kGeneric narrow stripes: full predicate and capture
+enum : int { kFast = 0, kHead = 1, kTail = 2, kGeneric = 3 };
 
 // One anti-diagonal step.  k = step inside the block (compile-time), pre = lane 0's inputs for
 // steps 2j, 2j+1 as (D of column-1, V of column) pairs, pa/pb = where this lane drops (D, V).
-template <bool CODES, bool PRED>
+template <bool CODES, int MODE>
 __device__ __forceinline__ void step16(const int k, StripState& S, const int4& pre, const unsigned mword,
-                                       int* pa, int* pb, const bool act, int& x1o,
-                                       int& x2o, int& x3o) {
+                                       int* pa, int* pb, const int t, const int lane, const int W,
+                                       const bool row_ok) {
     const int f = (int)__builtin_amdgcn_ubfe(mword, 4 * (k & 7), 4);
     const int preD = (k & 1) ? pre.z : pre.x;
     const int preV = (k & 1) ? pre.w : pre.y;
@@ -132,14 +142,13 @@ __device__ __forceinline__ void step16(const int k, StripState& S, const int4& p
     const int Hn = max(D, x2p);
     const int Vn = max(D, x3p);
     if (CODES) push_bits6(S.aD, S.aH, S.aV, x1, x2, x3, x2p, x3p, D, Hn, Vn);
-    if (PRED) {
-        if (act) {
-            if (k & 1) S.D1 = D; else S.D0 = D;
-            S.H = Hn;
-            S.V = Vn;
-        }
-        x1o = x1; x2o = x2; x3o = x3;
-    } else {
+    if (MODE == kTail || MODE == kGeneric) {
+        if (lane == t - (W - 1)) { S.r1 = x1; S.r2 = x2; S.r3 = x3; }
+    }
+    bool act = true;
+    if (MODE == kHead) act = lane <= t;
+    if (MODE == kGeneric) act = row_ok && lane <= t && t - lane < W;
+    if (act) {
         if (k & 1) S.D1 = D; else S.D0 = D;
         S.H = Hn;
         S.V = Vn;
@@ -148,6 +157,20 @@ __device__ __forceinline__ void step16(const int k, StripState& S, const int4& p
     const int Dc = (k & 1) ? S.D1 : S.D0;
     if (k + 1 < kBlk) pa[2 * (k + 1) + 1] = S.V; else pb[2 * (k + 1 - kBlk) + 1] = S.V;
     if (k + 2 < kBlk) pa[2 * (k + 2)] = Dc; else pb[2 * (k + 2 - kBlk)] = Dc;
+}
+
+// LDS counters: the LDS executes one wavefront's instructions in order, so data written before
+// a counter is visible before it and reads issued before a counter store are done before it.
+// Only the COMPILER must keep the order; release/acquire atomics would also drain the vector
+// memory counter (table prefetch, code stores, granules) once per block -- a microsecond each.
+#define PSA_COMPILER_BARRIER() asm volatile("" ::: "memory")
+__device__ __forceinline__ int lds_peek(int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_post(int* p, int v) {
+    PSA_COMPILER_BARRIER();
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    PSA_COMPILER_BARRIER();
 }
 
 __device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* abort_flag, unsigned limit = 1u << 25) {
@@ -162,31 +185,252 @@ __device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* abort_fl
     return false;
 }
 
+// Everything one strip carries from block to block.  Members marked (u) are wave-uniform and
+// live in SGPRs (they derive from readfirstlane'd values and kernel arguments).
+template <bool CODES>
+struct StripCtx {
+    StripState S;
+    int lane;
+    int wv;                 // (u) wave inside the workgroup
+    int W, nblocks;         // (u)
+    bool from_lds, to_lds, to_hbm, top_analytic;  // (u)
+    bool row_ok;
+    int64_t sg, c0, i, R, y_row;                  // sg, c0, R (u)
+    // substitution table window
+    const uint32_t* trow;
+    int msh, mword_idx;
+    unsigned mw[9];         // table words covering this superblock's 64 columns (+ alignment spill)
+    int prod_seen;          // (u) last value read from the producer's counter
+    // hand-off
+    int2* my_ring;
+    int* out_base;
+    int out_wrap;
+    int* prod_post;         // lane 63 of an LDS producer: the consumer's prod counter; else a dump word
+    int* cons_post;         // lane 0 of an LDS consumer: its cons counter; else a dump word
+    const u64* gin;
+    u64* gout;
+    u64 tag_in, tag_out;
+    int carryD;
+    u64 gq[4];              // granules requested for blocks 0..3 of the next superblock (wave 0 path)
+    unsigned gq_valid;      // (u) bit j: gq[j] holds a request
+    unsigned wait_in, wait_room;  // (u) spin iterations, for the profile only
+#ifdef PSA_EXP_TIMING
+    unsigned tsec[4];
+#endif
+};
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// Where a strip's row-above comes from / where its last row goes.  The steady-state loop is
+// compiled once per role so that a role's code holds only its own memory operations (a wait on
+// the vector-memory counter placed for one role's loads would stall every other role too);
+// kAny = decided at run time from the context flags (head and tail of a strip).
+enum : int { kAny = -1, kInLds = 0, kInHbm = 1, kInTop = 2, kOutLds = 0, kOutHbm = 1, kOutNone = 2 };
+
+// One block of 16 steps: wait for lane 0's inputs, load them, run the steps, post progress.
+template <bool CODES, int MODE, int IN, int OUT, int JB>
+__device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, const int t0,
+                                          const unsigned mlo, const unsigned mhi) {
+    const int lane = c.lane;
+    const int W = c.W;
+    const bool from_lds = (IN == kAny) ? c.from_lds : (IN == kInLds);
+    const bool top_analytic = (IN == kAny) ? c.top_analytic : (IN == kInTop);
+    const bool to_hbm = (OUT == kAny) ? c.to_hbm : (OUT == kOutHbm);
+    // ---- 1. lane 0's inputs for columns t0..t0+15: ring slots t0+64..t0+79 ----
+    const int slot0 = (t0 + 64) & (kRing - 1);
+    if (from_lds) {
+        if (MODE == kFast || MODE == kHead || t0 < W) {
+            // slots t0+64..t0+79 are complete once the producer has finished step t0+78; it stops at nblocks*16
+            const int need = min(t0 + 80, c.nblocks * kBlk);
+            if (c.prod_seen < need) {
+                unsigned spins = 0;
+                while ((c.prod_seen = __builtin_amdgcn_readfirstlane(lds_peek(&lds.prod[c.wv]))) < need) {
+                    if (spin_expired(spins, p.abort_flag)) return false;
+                }
+                c.wait_in += spins;
+            }
+        }
+    } else if (MODE == kFast || MODE == kHead || t0 < W) {
+        // wave 0: fetch (D, V) of the row above for 16 columns into lanes 0..15, write the ring itself
+        int gD, gV;
+        const int col = t0 + lane;
+        const bool col_ok = lane < kBlk && col < W;
+        if (top_analytic) {
+            int t1, t2, t3;
+            const int64_t j = c.c0 + 1 + col;
+            boundary_triple(0, j, t1, t2, t3);
+            gD = max3i(t1, t2, t3) + (int)(3 * j);
+            gV = max3i(t1, t2, t3 + 2) + (int)(3 * j);
+        } else {
+            // granules of this block were requested one superblock (four blocks) ago; if the strip above
+            // had not published them yet, poll until it has
+            unsigned spins = 0;
+            u64 g = c.gq[JB];
+            bool have = (c.gq_valid >> JB) & 1;
+#ifdef PSA_EXP_HANDOFF
+            const u64 tlook = wall_clock64();
+            const bool pre_ok = have;
+#endif
+            for (;;) {
+                if (!have) g = col_ok ? load_granule(c.gin + col) : (c.tag_in << 32);
+                have = false;
+                const bool ok = !col_ok || (g >> 32) == c.tag_in;
+                if (__all(ok)) break;
+                if (spin_expired(spins, p.abort_flag, 1u << 22)) return false;
+            }
+            c.wait_in += spins;
+#ifdef PSA_EXP_HANDOFF
+            if (p.prof && lane == 0) {
+                u64* dbg = p.prof + 4 * (((p.r1 - p.r0) + 63) >> 6) + ((c.sg * (u64)c.nblocks + (t0 >> 4)) * 4);
+                dbg[0] = tlook; dbg[1] = wall_clock64(); dbg[2] = ((u64)pre_ok << 32) | spins;
+            }
+#endif
+            gD = (int)((unsigned)g >> 2);
+            gV = gD + (int)((unsigned)g & 3u);
+            // request the same block of the next superblock
+            const int ncol = col + 64;
+            const bool nvalid = (t0 + 64 < W);
+            if (nvalid) c.gq[JB] = (lane < kBlk && ncol < W) ? load_granule(c.gin + ncol) : (c.tag_in << 32);
+            c.gq_valid = (c.gq_valid & ~(1u << JB)) | ((unsigned)nvalid << JB);
+        }
+        // slot(col) = (D of col-1, V of col)
+        const int Dm1 = shift_down1(c.carryD, gD);
+        c.carryD = __builtin_amdgcn_readlane(gD, kBlk - 1);
+        if (lane < kBlk) c.my_ring[slot0 + lane] = make_int2(Dm1, gV);
+    }
+    const int4* rp = (const int4*)(c.my_ring + slot0);
+    int4 pre[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pre[j] = rp[j];
+    if (IN == kAny || IN == kInLds) lds_post(c.cons_post, t0 + 80);
+
+    int* pa = c.out_base + (c.out_wrap ? ((2 * t0) & (c.out_wrap - 1)) : 0);
+    int* pb = c.out_base + (c.out_wrap ? ((2 * (t0 + kBlk)) & (c.out_wrap - 1)) : 0);
+
+    // ---- 2. the sixteen steps ----
+#pragma unroll
+    for (int k = 0; k < kBlk; ++k)
+        step16<CODES, MODE>(k, c.S, pre[k >> 1], (k < 8) ? mlo : mhi, pa, pb, t0 + k, lane, W, c.row_ok);
+
+    // ---- 3. publish progress / flush granules ----
+    if (OUT == kAny || OUT == kOutLds) lds_post(c.prod_post, t0 + kBlk);
+    if (to_hbm) {
+        // columns t0-64 .. t0-49 were completed by the end of this block (lane 63, step = column + 63)
+        const int cb = t0 - 64;
+        if (cb >= 0 && cb < W) {
+            const int col = cb + lane;
+            if (lane < kBlk && col < W) {
+                // staging slot of column c is c + 64 (numbered like the ring): V in .y of the slot, D in .x of the next
+                const int vs = lds.stage[c.wv][(col + 64) & 31].y;
+                const int ds = lds.stage[c.wv][(col + 65) & 31].x;
+                store_granule(c.gout + col, (c.tag_out << 32) | ((unsigned)ds << 2) | (unsigned)(vs - ds));
+            }
+            PSA_COMPILER_BARRIER();
+#ifdef PSA_EXP_HANDOFF
+            if (p.prof && lane == 0) {
+                // consumer strip sg+1, its block cb/16
+                u64* dbg = p.prof + 4 * (((p.r1 - p.r0) + 63) >> 6) + (((c.sg + 1) * (u64)c.nblocks + (cb >> 4)) * 4);
+                dbg[3] = wall_clock64();
+            }
+#endif
+        }
+    }
+    return true;
+}
+
+// Four blocks = 64 steps.  Everything that touches vector memory on a fixed schedule happens
+// here, once per 64 steps, so that no wait on the vector-memory counter sits in the 16-step
+// path: the substitution-table words of the NEXT superblock are requested at the start of
+// this one, the winner bits of this one are stored at its end.
+template <bool CODES, int MODE, int IN, int OUT>
+__device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, const int sb) {
+    const int t0 = sb * 64;
+#ifdef PSA_EXP_MID
+    if (p.prof && c.lane == 0 && sb == p.Q / 2) p.prof[4 * ((c.sg << 6) - p.r0 >> 6) + 2] = wall_clock64();
+#endif
+    // table words one superblock ahead (8 new words; word 8 of the current set is word 0 of the next)
+    const u32x4_a4 n0 = *(const u32x4_a4*)(c.trow + c.mword_idx + 9);
+    const u32x4_a4 n1 = *(const u32x4_a4*)(c.trow + c.mword_idx + 13);
+    // room in the consumer's ring for the slots this superblock writes (up to t0 + 65)
+    if ((OUT == kAny) ? c.to_lds : (OUT == kOutLds)) {
+        unsigned spins = 0;
+        while (__builtin_amdgcn_readfirstlane(lds_peek(&lds.cons[c.wv + 1])) < t0 + 66 - kRing) {
+            if (spin_expired(spins, p.abort_flag)) return false;
+        }
+        c.wait_room += spins;
+    }
+    uint4 cD, cH, cV;
+#define PSA_BLOCK(j)                                                                                   \
+    {                                                                                                  \
+        const unsigned mlo = __builtin_amdgcn_alignbit(c.mw[2 * j + 1], c.mw[2 * j], c.msh);           \
+        const unsigned mhi = __builtin_amdgcn_alignbit(c.mw[2 * j + 2], c.mw[2 * j + 1], c.msh);       \
+        if (!run_block<CODES, MODE, IN, OUT, j>(c, lds, p, t0 + j * kBlk, mlo, mhi)) return false;     \
+    }
+    PSA_BLOCK(0)
+    if (CODES) { cD.x = c.S.aD; cH.x = c.S.aH; cV.x = c.S.aV; }
+    PSA_BLOCK(1)
+    if (CODES) { cD.y = c.S.aD; cH.y = c.S.aH; cV.y = c.S.aV; }
+    PSA_BLOCK(2)
+    if (CODES) { cD.z = c.S.aD; cH.z = c.S.aH; cV.z = c.S.aV; }
+    PSA_BLOCK(3)
+    if (CODES) { cD.w = c.S.aD; cH.w = c.S.aH; cV.w = c.S.aV; }
+#undef PSA_BLOCK
+    if (CODES) {
+        uint4* dst = (uint4*)(p.codes + code_word_index(c.sg, p.Q, sb, 0, c.lane, 0));
+        dst[0] = cD; dst[64] = cH; dst[128] = cV;
+    }
+    c.mw[0] = c.mw[8];
+    c.mw[1] = n0.x; c.mw[2] = n0.y; c.mw[3] = n0.z; c.mw[4] = n0.w;
+    c.mw[5] = n1.x; c.mw[6] = n1.y; c.mw[7] = n1.z; c.mw[8] = n1.w;
+    c.mword_idx += 8;
+    return true;
+}
+
+template <bool CODES, int IN, int OUT>
+__device__ __forceinline__ bool run_steady(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
+    // superblock 0 is the head (lanes entering), then the unpredicated steady state
+    if (lo == 0 && hi > 0) {
+        if (!run_superblock<CODES, kHead, IN, OUT>(c, lds, p, 0)) return false;
+        lo = 1;
+    }
+    for (int sb = lo; sb < hi; ++sb)
+        if (!run_superblock<CODES, kFast, IN, OUT>(c, lds, p, sb)) return false;
+    return true;
+}
+
+template <bool CODES, int IN>
+__device__ __forceinline__ bool run_steady_out(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
+    if (c.to_lds) return run_steady<CODES, IN, kOutLds>(c, lds, p, lo, hi);
+    if (c.to_hbm) return run_steady<CODES, IN, kOutHbm>(c, lds, p, lo, hi);
+    return run_steady<CODES, IN, kOutNone>(c, lds, p, lo, hi);
+}
+
 template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) void fill_strips_v2(FillArgs2 q) {
     __shared__ FillLds lds;
     __shared__ unsigned wg_ticket;
     const FillArgs& p = q.base;
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    StripCtx<CODES> c;
+    const int lane = c.lane = threadIdx.x & 63;
+    const int wv = c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) wg_ticket = atomicAdd(p.ticket, 1u);
     if (threadIdx.x < kNW) { lds.prod[threadIdx.x] = 0; lds.cons[threadIdx.x] = 0; }
     __syncthreads();
-    const int64_t R = p.r1 - p.r0;
+    const int64_t R = c.R = p.r1 - p.r0;
     const int64_t strips = (R + 63) >> 6;
-    const int64_t s = (int64_t)wg_ticket * kNW + wv;  // strip inside the chunk
+    const int64_t s = (int64_t)__builtin_amdgcn_readfirstlane(wg_ticket) * kNW + wv;  // strip inside the chunk
     if (s >= strips) return;
     const int64_t row_base = p.r0 + 64 * s;
-    const int64_t sg = row_base >> 6;
-    const int64_t i = row_base + lane + 1;
-    const bool row_ok = i <= p.r1;
-    const int W = p.W;
-    const int64_t c0 = p.c0;
+    const int64_t sg = c.sg = row_base >> 6;
+    const int64_t i = c.i = row_base + lane + 1;
+    const bool row_ok = c.row_ok = i <= p.r1;
+    const int W = c.W = p.W;
+    const int64_t c0 = c.c0 = p.c0;
     const bool last_in_chunk = (s == strips - 1);
-    const bool to_lds = (wv + 1 < kNW) && !last_in_chunk;          // strip s+1 is wave wv+1 of this workgroup
-    const bool to_hbm = !to_lds && !(last_in_chunk && p.r1 == p.n);  // someone (maybe a later launch) reads it
-    const bool from_lds = wv > 0;
-    const bool top_analytic = (sg == 0);
+    c.to_lds = (wv + 1 < kNW) && !last_in_chunk;              // strip s+1 is wave wv+1 of this workgroup
+    c.to_hbm = !c.to_lds && !(last_in_chunk && p.r1 == p.n);  // someone (maybe a later launch) reads it
+    c.from_lds = wv > 0;
+    c.top_analytic = (sg == 0);
 
     // ---- left boundary (as v1) ----
     int o1, o2, o3, u1, u2, u3;
@@ -205,190 +449,98 @@ __global__ __launch_bounds__(kNW * 64) void fill_strips_v2(FillArgs2 q) {
     const int bias_own = (int)(3 * (i + c0));
     const int D_own = max3i(o1, o2, o3) + bias_own;
     const int D_up = max3i(u1, u2, u3) + bias_own - 3;
-    StripState S;
-    S.D0 = S.D1 = D_own;
-    S.H = max3i(o1, o2 + 2, o3) + bias_own;
-    S.V = 0;
-    S.aD = S.aH = S.aV = 0;
+    c.S.D0 = c.S.D1 = D_own;
+    c.S.H = max3i(o1, o2 + 2, o3) + bias_own;
+    c.S.V = 0;
+    c.S.aD = c.S.aH = c.S.aV = 0;
+    c.S.r1 = c.S.r2 = c.S.r3 = 0;
+    c.y_row = i - p.r0 - 1;
 
     // ---- substitution table row of this lane; window of 16 columns starting at t0 - lane ----
     const int sym = row_ok ? (int)q.a_ids[i - 1] : 0;
-    const uint32_t* trow = q.eqtab + (size_t)sym * q.tab_pitch + kTabPad;
-    const int msh = 4 * ((64 - lane) & 7);                      // (t0 - lane) mod 8 nibbles, t0 % 16 == 0
-    int mword_idx = (-lane - ((64 - lane) & 7)) / 8;            // floor((0 - lane) / 8), exact division
-    unsigned mw0 = trow[mword_idx];
+    c.trow = q.eqtab + (size_t)sym * q.tab_pitch + kTabPad;
+    c.msh = 4 * ((64 - lane) & 7);                      // (t0 - lane) mod 8 nibbles, t0 % 16 == 0
+    c.mword_idx = (-lane - ((64 - lane) & 7)) / 8;      // floor((0 - lane) / 8), exact division
+#pragma unroll
+    for (int j = 0; j < 9; ++j) c.mw[j] = c.trow[c.mword_idx + j];
+    c.prod_seen = 0;
 
     // ---- hand-off plumbing ----
-    int2* my_ring = lds.ring[wv];
-    int* out_base;      // lane 63: where its (D, V) go; other lanes: a private dump
-    int out_wrap;       // ints after which out_base wraps (ring size), 0 = no wrapping (dump)
-    if (lane == 63 && to_lds) { out_base = (int*)lds.ring[wv + 1]; out_wrap = kRing * 2; }
-    else if (lane == 63 && to_hbm) { out_base = (int*)lds.stage[wv]; out_wrap = 32 * 2; }
-    else { out_base = lds.dummy[wv] + lane; out_wrap = 0; }
-    const u64 tag_in = (u64)sg, tag_out = (u64)(sg + 1);
-    const u64* gin = p.ring + (size_t)(((sg - 1) / kNW) & 1) * p.Wpad;  // bottom row of strip sg-1
-    u64* gout = p.ring + (size_t)((sg / kNW) & 1) * p.Wpad;
-    int carryD = D_up;          // D of column t0-1 of the row above (wave 0 path)
-    u64 gpre = 0;               // prefetched granule of the next block (wave 0 path, lanes 0..15)
-    bool gpre_valid = false;
+    c.my_ring = lds.ring[wv];
+    if (lane == 63 && c.to_lds) { c.out_base = (int*)lds.ring[wv + 1]; c.out_wrap = kRing * 2; }
+    else if (lane == 63 && c.to_hbm) { c.out_base = (int*)lds.stage[wv]; c.out_wrap = 32 * 2; }
+    else { c.out_base = lds.dummy[wv] + lane; c.out_wrap = 0; }
+    c.prod_post = (lane == 63 && c.to_lds) ? &lds.prod[wv + 1] : &lds.dummy2[wv][lane];
+    c.cons_post = (lane == 0 && c.from_lds) ? &lds.cons[wv] : &lds.dummy2[wv][lane];
+    c.tag_in = (u64)sg;
+    c.tag_out = (u64)(sg + 1);
+    c.gin = p.ring + (size_t)(((sg - 1) / kNW) & 1) * p.Wpad;  // bottom row of strip sg-1
+    c.gout = p.ring + (size_t)((sg / kNW) & 1) * p.Wpad;
+    c.carryD = D_up;          // D of column t0-1 of the row above (wave 0 path)
+    c.gq[0] = c.gq[1] = c.gq[2] = c.gq[3] = 0;
+    c.gq_valid = 0;
+    c.wait_in = c.wait_room = 0;
+#ifdef PSA_EXP_TIMING
+    c.tsec[0] = c.tsec[1] = c.tsec[2] = c.tsec[3] = 0;
+#endif
 
-    const int nblocks = p.Q * (64 / kBlk);
+    const int nblocks = c.nblocks = p.Q * (64 / kBlk);
     if (p.prof && lane == 0) {
-        unsigned hwid;
+        unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         p.prof[4 * s + 0] = wall_clock64();
         p.prof[4 * s + 2] = ((u64)xcc << 32) | hwid;
     }
-    uint4 cD = {0, 0, 0, 0}, cH = {0, 0, 0, 0}, cV = {0, 0, 0, 0};
-    const int64_t y_row = i - p.r0 - 1;
+#ifdef PSA_EXP_TIMING
+    const unsigned long long tc0 = __builtin_readcyclecounter();
+#endif
 
-    for (int blk = 0; blk < nblocks; ++blk) {
-        const int t0 = blk * kBlk;
-        // ---- 1. lane 0's inputs for columns t0..t0+15: ring slots t0+64..t0+79 ----
-        const int slot0 = (t0 + 64) & (kRing - 1);
-        if (from_lds) {
-            if (t0 < W) {
-                unsigned spins = 0;
-                // slots t0+64..t0+79 are complete once the producer has finished step t0+78; it stops at nblocks*16
-                const int need = min(t0 + 80, nblocks * kBlk);
-                while (__hip_atomic_load(&lds.prod[wv], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-                    if (spin_expired(spins, p.abort_flag)) return;
-                }
-            }
-        } else {
-            // wave 0: fetch (D, V) of the row above for 16 columns into lanes 0..15, write the ring itself
-            int gD = 0, gV = 0;
-            if (t0 < W) {
-                const int col = t0 + lane;
-                const bool col_ok = lane < kBlk && col < W;
-                if (top_analytic) {
-                    int t1, t2, t3;
-                    const int64_t j = c0 + 1 + col;
-                    boundary_triple(0, j, t1, t2, t3);
-                    gD = max3i(t1, t2, t3) + (int)(3 * j);
-                    gV = max3i(t1, t2, t3 + 2) + (int)(3 * j);
-                } else {
-                    unsigned spins = 0;
-                    u64 g = gpre;
-                    bool have = gpre_valid;
-                    for (;;) {
-                        if (!have) g = col_ok ? load_granule(gin + col) : (tag_in << 32);
-                        have = false;
-                        const bool ok = !col_ok || (g >> 32) == tag_in;
-                        if (__all(ok)) break;
-                        if (spin_expired(spins, p.abort_flag, 1u << 22)) return;
-                    }
-                    gD = (int)((unsigned)g >> 2);
-                    gV = gD + (int)((unsigned)g & 3u);
-                    // prefetch the next block's granules; validated when that block starts
-                    const int ncol = col + kBlk;
-                    gpre_valid = (t0 + kBlk < W);
-                    if (gpre_valid) gpre = (lane < kBlk && ncol < W) ? load_granule(gin + ncol) : (tag_in << 32);
-                }
-                // slot(col) = (D of col-1, V of col)
-                const int Dm1 = shift_down1(carryD, gD);
-                carryD = __builtin_amdgcn_readlane(gD, kBlk - 1);
-                if (lane < kBlk) my_ring[slot0 + lane] = make_int2(Dm1, gV);
-            }
+    // Wide stripes: head + steady state compiled per role, then a tail that captures the right
+    // boundary.  Narrow stripes (W < 128): one generic, fully predicated loop.
+    if (W >= 128) {
+        const int fast_hi = (W - 1) / 64;  // superblock sb is steady iff 64 sb + 64 <= W - 1
+        bool ok;
+        if (c.from_lds) ok = run_steady_out<CODES, kInLds>(c, lds, p, 0, fast_hi);
+        else if (c.top_analytic) ok = run_steady_out<CODES, kInTop>(c, lds, p, 0, fast_hi);
+        else ok = run_steady_out<CODES, kInHbm>(c, lds, p, 0, fast_hi);
+        if (!ok) return;
+        for (int sb = fast_hi; sb < p.Q; ++sb)
+            if (!run_superblock<CODES, kTail, kAny, kAny>(c, lds, p, sb)) return;
+    } else {
+        for (int sb = 0; sb < p.Q; ++sb)
+            if (!run_superblock<CODES, kGeneric, kAny, kAny>(c, lds, p, sb)) return;
+    }
+    // right boundary / final triple, captured when each lane passed column W-1
+    if (row_ok) {
+        const int bias = (int)(3 * (i + c0 + W));
+        if (p.right) {
+            p.right[c.y_row] = c.S.r1 - bias; p.right[R + c.y_row] = c.S.r2 - bias; p.right[2 * R + c.y_row] = c.S.r3 - bias;
         }
-        const int4* rp = (const int4*)(my_ring + slot0);
-        int4 pre[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pre[j] = rp[j];
-        if (from_lds && lane == 0)
-            __hip_atomic_store(&lds.cons[wv], t0 + 80, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-
-        // ---- 2. substitution nibbles for this lane's 16 columns ----
-        const unsigned mw1 = trow[mword_idx + 1], mw2 = trow[mword_idx + 2];
-        const unsigned mlo = __builtin_amdgcn_alignbit(mw1, mw0, msh);
-        const unsigned mhi = __builtin_amdgcn_alignbit(mw2, mw1, msh);
-        mw0 = mw2;
-        mword_idx += 2;
-
-        // ---- 3. room in the consumer's ring (slots up to t0+17 are written by this block) ----
-        if (to_lds) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(&lds.cons[wv + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                   t0 + 18 - kRing) {
-                if (spin_expired(spins, p.abort_flag)) return;
-            }
-        }
-        int* pa = out_base + (out_wrap ? ((2 * t0) & (out_wrap - 1)) : 0);
-        int* pb = out_base + (out_wrap ? ((2 * (t0 + kBlk)) & (out_wrap - 1)) : 0);
-
-        // ---- 4. the sixteen steps ----
-        const bool fast = (t0 >= 64) && (t0 + kBlk <= W - 1);
-        if (fast) {
-            int d0, d1, d2;
-#pragma unroll
-            for (int k = 0; k < kBlk; ++k)
-                step16<CODES, false>(k, S, pre[k >> 1], (k < 8) ? mlo : mhi, pa, pb, true, d0, d1, d2);
-        } else {
-#pragma unroll
-            for (int k = 0; k < kBlk; ++k) {
-                const int jj = t0 + k - lane;
-                const bool act = row_ok && jj >= 0 && jj < W;
-                int x1, x2, x3;
-                step16<CODES, true>(k, S, pre[k >> 1], (k < 8) ? mlo : mhi, pa, pb, act, x1, x2, x3);
-                if (act && jj == W - 1) {
-                    const int bias = (int)(3 * (i + c0 + W));
-                    if (p.right) {
-                        p.right[y_row] = x1 - bias; p.right[R + y_row] = x2 - bias; p.right[2 * R + y_row] = x3 - bias;
-                    }
-                    if (i == p.n) {
-                        p.final_triple[0] = x1 - bias; p.final_triple[1] = x2 - bias; p.final_triple[2] = x3 - bias;
-                    }
-                }
-            }
-        }
-
-        // ---- 5. publish progress / flush granules ----
-        if (to_lds) {
-            if (lane == 63) __hip_atomic_store(&lds.prod[wv + 1], t0 + kBlk, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else if (to_hbm) {
-            // columns t0-64 .. t0-49 were completed by the end of this block (lane 63, step k = column + 63)
-            const int cb = t0 - 64;
-            if (cb >= 0 && cb < W) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const int col = cb + lane;
-                if (lane < kBlk && col < W) {
-                    // staging slot of column c is c + 64 (same numbering as the ring): V in .y of slot, D in .x of slot+1
-                    const int vs = lds.stage[wv][(col + 64) & 31].y;
-                    const int ds = lds.stage[wv][(col + 65) & 31].x;
-                    store_granule(gout + col, (tag_out << 32) | ((unsigned)ds << 2) | (unsigned)(vs - ds));
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-
-        // ---- 6. winner bits: one dword per 16 steps per aggregate, stored 16 bytes per lane every 64 steps ----
-        if (CODES) {
-            const int d = blk & 3;
-            if (d == 0) { cD.x = S.aD; cH.x = S.aH; cV.x = S.aV; }
-            else if (d == 1) { cD.y = S.aD; cH.y = S.aH; cV.y = S.aV; }
-            else if (d == 2) { cD.z = S.aD; cH.z = S.aH; cV.z = S.aV; }
-            else {
-                cD.w = S.aD; cH.w = S.aH; cV.w = S.aV;
-                uint4* dst = (uint4*)(p.codes + code_word_index(sg, p.Q, blk >> 2, 0, lane, 0));
-                dst[0] = cD; dst[64] = cH; dst[128] = cV;
-            }
+        if (i == p.n) {
+            p.final_triple[0] = c.S.r1 - bias; p.final_triple[1] = c.S.r2 - bias; p.final_triple[2] = c.S.r3 - bias;
         }
     }
-    if (p.prof && lane == 0) p.prof[4 * s + 1] = wall_clock64();
+
+    if (p.prof && lane == 0) {
+        p.prof[4 * s + 1] = wall_clock64();
+#ifdef PSA_EXP_TIMING
+        p.prof[4 * s + 2] = ((u64)c.tsec[0] << 32) | c.tsec[1];
+        p.prof[4 * s + 3] = ((u64)c.tsec[2] << 32) | c.tsec[3];
+#else
+        p.prof[4 * s + 3] = ((u64)c.wait_room << 32) | c.wait_in;
+#endif
+    }
     // ---- trailing granule group (columns whose flush block lies beyond the last block) ----
-    if (to_hbm) {
+    if (c.to_hbm) {
         for (int cb = nblocks * kBlk - 64; cb < W; cb += kBlk) {
             if (cb < 0) continue;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            PSA_COMPILER_BARRIER();
             const int col = cb + lane;
             if (lane < kBlk && col < W) {
                 const int vs = lds.stage[wv][(col + 64) & 31].y;
                 const int ds = lds.stage[wv][(col + 65) & 31].x;
-                store_granule(gout + col, (tag_out << 32) | ((unsigned)ds << 2) | (unsigned)(vs - ds));
+                store_granule(c.gout + col, (c.tag_out << 32) | ((unsigned)ds << 2) | (unsigned)(vs - ds));
             }
         }
     }
