@@ -321,7 +321,11 @@ int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io,
     ta.codes = s->codes; ta.c0 = s->c0; ta.W = s->W; ta.Q = s->Q; ta.cap = s->tb_cap;
     ta.out_ai = s->tb_ai; ta.out_bj = s->tb_bj; ta.state = s->tb_state;
     HIP_TRY(hipEventRecord(s->ev[2], st));
-    hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
+    {
+        const char* force = getenv("PSA_TRACEBACK_KERNEL");
+        if (force && !strcmp(force, "v1")) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
+        else hipLaunchKernelGGL(psa::traceback_v2, dim3(1), dim3(64), 0, st, ta);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[3], st));
     s->tb_timed = true;

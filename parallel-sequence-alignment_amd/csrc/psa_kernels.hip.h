@@ -230,4 +230,139 @@ __global__ __launch_bounds__(64) void traceback_v1(TraceArgs p) {
     p.state[0] = i; p.state[1] = j; p.state[2] = k; p.state[3] = done; p.state[4] = len; p.state[5] = err;
 }
 
+
+// ---- traceback, wave-cooperative (production) ----
+// The packed winner bits are stored in tiles of 64 rows x 64 wavefront steps (3 KB: three
+// aggregates x 64 lanes x 16 bytes), the unit the fill kernel writes.  One wavefront walks:
+//   * tiles are cached in LDS; on a miss the tile and the next tiles a pure diagonal would
+//     visit are fetched together (one memory latency per batch instead of per tile);
+//   * while the walk is in table 1 and the predecessor's "table 1 wins" bit is set it moves on a
+//     diagonal: all 64 lanes test their own row's bit at once, a ballot gives the run length
+//     inside the tile and the lanes emit the run's columns in parallel;
+//   * everything else is one scalar step (same semantics as traceback_v1).
+constexpr int kTbSlots = 16;
+constexpr int kTbBatch = 8;
+
+__global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
+    __shared__ uint4 tile[kTbSlots][3][64];
+    __shared__ long long slot_tile[kTbSlots];
+    const int lane = threadIdx.x;
+    int64_t i = p.state[0], j = p.state[1];
+    int k = (int)p.state[2];
+    int64_t len = 0, done = 0, err = 0;
+    const int64_t c0 = p.c0;
+    const int64_t Q = p.Q;
+    if (lane < kTbSlots) slot_tile[lane] = -1;
+    __syncthreads();
+    int victim = 0;
+    const uint4* codes4 = (const uint4*)p.codes;
+
+    auto lookup = [&](long long T) -> int {
+        const long long id = slot_tile[lane & (kTbSlots - 1)];
+        const unsigned long long m = __ballot(lane < kTbSlots && id == T);
+        return m ? (int)__builtin_ctzll(m) : -1;
+    };
+
+    for (;;) {
+        if (i == 0 || j == 0) { done = 1; break; }
+        const int64_t pi = i - (k != 2), pj = j - (k != 3);
+        if (c0 > 0 && pj <= c0) break;  // predecessor belongs to the stripe on the left
+        int w;
+        if (pi == 0 || pj == 0) {
+            int t1, t2, t3;
+            boundary_triple(pi, pj, t1, t2, t3);
+            w = winner_plain(t1, t2, t3, k);
+        } else {
+            const int64_t strip = (pi - 1) >> 6;
+            const int lp = (int)((pi - 1) & 63);
+            const int64_t t = (pj - c0 - 1) + lp;
+            const int64_t q = t >> 6;
+            const long long T = strip * Q + q;
+            int slot = lookup(T);
+            if (slot < 0) {
+                // fetch T and the tiles a diagonal continuation would visit next
+                long long ids[kTbBatch];
+                int64_t cpi = pi, cpj = pj;
+#pragma unroll
+                for (int b = 0; b < kTbBatch; ++b) {
+                    ids[b] = -1;
+                    if (cpi >= 1 && cpj >= c0 + 1) {
+                        const int64_t bs = (cpi - 1) >> 6;
+                        const int bl = (int)((cpi - 1) & 63);
+                        const int64_t bt = (cpj - c0 - 1) + bl;
+                        const int64_t bq = bt >> 6;
+                        const long long Tb = bs * Q + bq;
+                        bool dup = lookup(Tb) >= 0;
+#pragma unroll
+                        for (int e = 0; e < b; ++e) dup = dup || ids[e] == Tb;
+                        if (!dup) ids[b] = Tb;
+                        const int64_t s1 = ((bt - (bq << 6)) >> 1) + 1, s2 = bl + 1;
+                        const int64_t sdiag = s1 < s2 ? s1 : s2;
+                        cpi -= sdiag; cpj -= sdiag;
+                    }
+                }
+                uint4 v[kTbBatch][3];
+#pragma unroll
+                for (int b = 0; b < kTbBatch; ++b) {
+                    if (ids[b] >= 0) {
+#pragma unroll
+                        for (int kind = 0; kind < 3; ++kind) v[b][kind] = codes4[(ids[b] * 3 + kind) * 64 + lane];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int b = 0; b < kTbBatch; ++b) {
+                    if (ids[b] >= 0) {
+#pragma unroll
+                        for (int kind = 0; kind < 3; ++kind) tile[victim][kind][lane] = v[b][kind];
+                        if (lane == 0) slot_tile[victim] = ids[b];
+                        victim = (victim + 1) & (kTbSlots - 1);
+                    }
+                }
+                __syncthreads();
+                slot = lookup(T);
+            }
+            if (k == 1) {
+                // diagonal run inside this tile: lane l' looks at cell (pi - d, pj - d), d = lp - l'
+                const int d = lp - lane;
+                const int64_t tt = t - 2 * d;
+                const bool valid = d >= 0 && tt >= (q << 6) && (pj - d) >= c0 + 1;
+                unsigned bit = 0;
+                if (valid) {
+                    const uint32_t* wp = (const uint32_t*)&tile[slot][0][lane];
+                    const uint32_t word = wp[(tt & 63) >> 4];
+                    bit = (word >> (2 * (15 - (int)(tt & 15)) + 1)) & 1u;
+                }
+                const unsigned long long mask = __ballot(valid && bit);
+                const unsigned long long upto = (lp == 63) ? ~0ull : ((1ull << (lp + 1)) - 1);
+                const unsigned long long inv = ~mask & upto;
+                const int r = inv ? lp - (63 - (int)__builtin_clzll(inv)) : lp + 1;
+                if (r > 0) {
+                    if (len + r > p.cap) { err = 1; break; }
+                    if (d >= 0 && d < r) {
+                        p.out_ai[len + d] = (int32_t)(pi - d);
+                        p.out_bj[len + d] = (int32_t)(pj - d);
+                    }
+                    len += r; i -= r; j -= r;
+                    continue;
+                }
+            }
+            const uint32_t* wp = (const uint32_t*)&tile[slot][k - 1][lp];
+            const uint32_t word = wp[(t & 63) >> 4];
+            const unsigned pair = (word >> (2 * (15 - (int)(t & 15)))) & 3u;
+            w = (pair & 2u) ? 1 : ((pair & 1u) ? 2 : 3);
+        }
+        if (len >= p.cap) { err = 1; break; }
+        if (lane == 0) {
+            p.out_ai[len] = (w == 2) ? -1 : (int32_t)(i - 1);
+            p.out_bj[len] = (w == 3) ? -1 : (int32_t)(j - 1);
+        }
+        ++len;
+        i = pi; j = pj; k = w;
+    }
+    if (lane == 0) {
+        p.state[0] = i; p.state[1] = j; p.state[2] = k; p.state[3] = done; p.state[4] = len; p.state[5] = err;
+    }
+}
+
 }  // namespace psa
