@@ -164,9 +164,9 @@ int psa_oracle_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m,
     return rc;
 }
 
-int psa_oracle_block(const uint8_t* a, const uint8_t* b, int64_t r0, int64_t r1, int64_t c0,
-                     int64_t c1, const int32_t* top[3], const int32_t* left[3],
-                     int32_t* bottom[3], int32_t* right[3]) {
+int psa_oracle_block_codes(const uint8_t* a, const uint8_t* b, int64_t r0, int64_t r1, int64_t c0,
+                           int64_t c1, const int32_t* top[3], const int32_t* left[3],
+                           int32_t* bottom[3], int32_t* right[3], uint8_t* codes) {
     const int64_t w = c1 - c0, h = r1 - r0;
     int32_t* rows = (int32_t*)malloc((size_t)(w + 1) * 6 * sizeof(int32_t));
     if (!rows) return -2;
@@ -178,8 +178,10 @@ int psa_oracle_block(const uint8_t* a, const uint8_t* b, int64_t r0, int64_t r1,
     if (right) for (int k = 0; k < 3; k++) if (right[k]) right[k][0] = top[k][w];
     for (int64_t y = 1; y <= h; y++) {
         k1[0] = left[0][y]; k2[0] = left[1][y]; k3[0] = left[2][y];
-        for (int64_t x = 1; x <= w; x++)
-            cell(a[r0 + y - 1], b[c0 + x - 1], u1, u2, u3, k1, k2, k3, x);
+        for (int64_t x = 1; x <= w; x++) {
+            uint8_t cw = cell(a[r0 + y - 1], b[c0 + x - 1], u1, u2, u3, k1, k2, k3, x);
+            if (codes) codes[(size_t)(y - 1) * (size_t)w + (size_t)(x - 1)] = cw;
+        }
         if (right) {
             if (right[0]) right[0][y] = k1[w];
             if (right[1]) right[1][y] = k2[w];
@@ -197,6 +199,12 @@ int psa_oracle_block(const uint8_t* a, const uint8_t* b, int64_t r0, int64_t r1,
     }
     free(rows);
     return 0;
+}
+
+int psa_oracle_block(const uint8_t* a, const uint8_t* b, int64_t r0, int64_t r1, int64_t c0,
+                     int64_t c1, const int32_t* top[3], const int32_t* left[3],
+                     int32_t* bottom[3], int32_t* right[3]) {
+    return psa_oracle_block_codes(a, b, r0, r1, c0, c1, top, left, bottom, right, NULL);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -61,6 +61,12 @@ int psa_oracle_block(const uint8_t* a, const uint8_t* b, int64_t r0, int64_t r1,
                      int64_t c1, const int32_t* top[3], const int32_t* left[3],
                      int32_t* bottom[3], int32_t* right[3]);
 
+/* Same, also writing the cell's packed winners w1 | w2<<2 | w3<<4 (destination-indexed, as in
+ * psa_oracle_align) to codes[(y-1)*(c1-c0) + (x-1)] for row r0+y, column c0+x. */
+int psa_oracle_block_codes(const uint8_t* a, const uint8_t* b, int64_t r0, int64_t r1, int64_t c0,
+                           int64_t c1, const int32_t* top[3], const int32_t* left[3],
+                           int32_t* bottom[3], int32_t* right[3], uint8_t* codes);
+
 /* Analytic boundary values of the reference (simple.cpp:116-133, simple.h:50). */
 void psa_oracle_boundary(int64_t i, int64_t j, int32_t t[3]);
 

@@ -1,0 +1,188 @@
+"""Column-stripe pipeline over several GPUs (one process per GPU, torch.distributed).
+
+This is the reference's own decomposition (simple.cpp:90-101, 261-277) lifted from threads to
+GPUs: rank g owns columns (c0, c1] of B with block = m // G and the last rank taking the
+remainder; rows are processed in chunks; for every chunk rank g receives the T1,T2,T3 triple of
+column c0 from rank g-1 (the mailbox of simple.cpp:136-154), fills its stripe, and sends the
+triple of column c1 to rank g+1 (simple.cpp:215-235).  The exchange is a chain of point-to-point
+messages (RCCL send/recv over xGMI with backend "nccl"), never a collective: 12 bytes per row
+and boundary.  The traceback walks right to left across the ranks, handing (i, j, k) over.
+
+The compute engine is pluggable only so that the orchestration can be exercised on CPU with
+gloo in the test-suite (tests inject an oracle-backed engine); the default and only product
+engine is the HIP stripe object of the C ABI.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .binding import Result, Stripe, finish_alignment, pick
+
+
+class HipStripeEngine:
+    """Stripe on the current GPU through the C ABI (include/psa.h psa_stripe_*)."""
+
+    def __init__(self, a, b, c0, c1, traceback=True):
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.stripe = Stripe(a, b, c0, c1, traceback=traceback)
+        self.n, self.m = self.stripe.n, self.stripe.m
+
+    def new_edge(self, rows):
+        return torch.empty(3 * rows, dtype=torch.int32, device=self.dev)
+
+    def fill_rows(self, r0, r1, left, right):
+        stream = torch.cuda.current_stream().cuda_stream
+        self.stripe.fill_rows(r0, r1, left.data_ptr() if left is not None else None,
+                              right.data_ptr() if right is not None else None, stream)
+
+    def final(self):
+        return self.stripe.final(torch.cuda.current_stream().cuda_stream)
+
+    def traceback(self, i, j, k):
+        cap = self.n + (self.stripe.c1 - self.stripe.c0) + 2
+        ai = np.zeros(cap, np.int32)
+        bj = np.zeros(cap, np.int32)
+        i, j, k, ln = self.stripe.traceback(i, j, k, ai, bj, 0, torch.cuda.current_stream().cuda_stream)
+        return i, j, k, ai[:ln], bj[:ln]
+
+    def close(self):
+        self.stripe.close()
+
+
+def stripe_bounds(m, world, rank):
+    """simple.cpp:90-99: block = m / p, stripe id starts at id*block, the last one takes the remainder."""
+    block = m // world
+    c0 = rank * block
+    c1 = m if rank == world - 1 else c0 + block
+    return c0, c1
+
+
+def _p2p_device(t):
+    """gloo moves host memory; nccl (RCCL) moves device memory."""
+    return t.cpu() if (dist.get_backend() == "gloo" and t.is_cuda) else t
+
+
+def _send(t, dst):
+    dist.send(_p2p_device(t).contiguous(), dst)
+
+
+def _recv(t, src):
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        tmp = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(tmp, src)
+        t.copy_(tmp)
+    else:
+        dist.recv(t, src)
+
+
+def align_striped(a, b, chunk_rows=4096, traceback=True, engine_cls=HipStripeEngine, keep_engine=None):
+    """Align A against B with B cut into world_size column stripes, one per rank.
+
+    Every rank calls this with the same a, b.  Returns Result(score, ai, bj) on every rank
+    (ai, bj are empty arrays when traceback is False).  chunk_rows (multiple of 64) is the
+    hand-off granularity between neighbouring ranks.
+    """
+    world, rank = dist.get_world_size(), dist.get_rank()
+    a = np.ascontiguousarray(np.frombuffer(a, np.uint8) if isinstance(a, (bytes, bytearray)) else a, np.uint8)
+    b = np.ascontiguousarray(np.frombuffer(b, np.uint8) if isinstance(b, (bytes, bytearray)) else b, np.uint8)
+    n, m = int(a.size), int(b.size)
+    assert chunk_rows >= 64 and chunk_rows % 64 == 0
+    empty = np.zeros(0, np.int32)
+    if n == 0 or m == 0:
+        # no cell to fill: the final pick reads the boundary (simple.cpp:246 after an empty loop)
+        t = (-1, 0, -(2 + m)) if n == 0 else (-1, -(2 + n), -1)
+        return Result(pick(*t)[1], empty, empty)
+
+    c0, c1 = stripe_bounds(m, world, rank)
+    width = c1 - c0
+    # ranks whose stripe is empty (m < world) only forward the boundary
+    owners = [g for g in range(world) if stripe_bounds(m, world, g)[1] > stripe_bounds(m, world, g)[0]]
+    prev_owner = max([g for g in owners if g < rank], default=None)
+    next_owner = min([g for g in owners if g > rank], default=None)
+    last_owner = owners[-1]
+
+    eng = None
+    if width > 0:
+        eng = keep_engine if keep_engine is not None else engine_cls(a, b, c0, c1, traceback)
+        left = eng.new_edge(min(chunk_rows, n)) if prev_owner is not None else None
+        right = eng.new_edge(min(chunk_rows, n)) if next_owner is not None else None
+        for r0 in range(0, n, chunk_rows):
+            r1 = min(n, r0 + chunk_rows)
+            rows = r1 - r0
+            lv = left[:3 * rows] if left is not None else None
+            rv = right[:3 * rows] if right is not None else None
+            if lv is not None:
+                _recv(lv, prev_owner)
+            eng.fill_rows(r0, r1, lv, rv)
+            if rv is not None:
+                _send(rv, next_owner)
+
+    # ---- final pick on the last stripe, then the traceback chain right -> left ----
+    if dist.get_backend() == "nccl":
+        comm_dev = torch.device("cuda", torch.cuda.current_device())
+    else:
+        comm_dev = torch.device("cpu")
+    head = torch.zeros(4, dtype=torch.int64, device=comm_dev)  # score, i, j, k
+    if rank == last_owner:
+        t = eng.final()
+        kstar, score = pick(*t)
+        head[0], head[1], head[2], head[3] = int(score), n, m, kstar
+    dist.broadcast(head, last_owner)
+    score = int(head[0].item())
+    if not traceback:
+        return Result(score, empty, empty)
+
+    pieces_ai, pieces_bj = empty, empty
+    state = torch.zeros(4, dtype=torch.int64, device=comm_dev)  # i, j, k, finished
+    if width > 0:
+        if rank == last_owner:
+            i, j, k, fin = n, m, int(head[3].item()), 0
+        else:
+            dist.recv(state, next_owner)
+            i, j, k, fin = (int(x) for x in state.tolist())
+        if not fin:
+            i, j, k, pieces_ai, pieces_bj = eng.traceback(i, j, k)
+            fin = int(i == 0 or j == 0)
+        if prev_owner is not None:
+            state[0], state[1], state[2], state[3] = i, j, k, fin
+            dist.send(state, prev_owner)
+    # gather the reversed pieces on rank 0: walk order is last stripe first
+    lens = torch.zeros(world, dtype=torch.int64, device=comm_dev)
+    mine = torch.tensor([len(pieces_ai)], dtype=torch.int64, device=comm_dev)
+    lens_list = [torch.zeros(1, dtype=torch.int64, device=comm_dev) for _ in range(world)]
+    dist.all_gather(lens_list, mine)
+    lens = [int(x.item()) for x in lens_list]
+    total = sum(lens)
+    packed = torch.from_numpy(np.concatenate([pieces_ai, pieces_bj]).astype(np.int32)).to(comm_dev)
+    if rank == 0:
+        ai_rev = np.zeros(total, np.int32)
+        bj_rev = np.zeros(total, np.int32)
+        pos = 0
+        for g in range(world - 1, -1, -1):
+            if lens[g] == 0:
+                continue
+            if g == 0:
+                buf = packed
+            else:
+                buf = torch.empty(2 * lens[g], dtype=torch.int32, device=comm_dev)
+                dist.recv(buf, g)
+            h = buf.cpu().numpy()
+            ai_rev[pos:pos + lens[g]] = h[:lens[g]]
+            bj_rev[pos:pos + lens[g]] = h[lens[g]:]
+            pos += lens[g]
+        ai, bj = finish_alignment(ai_rev, bj_rev, n, m)
+        out_len = torch.tensor([len(ai)], dtype=torch.int64, device=comm_dev)
+    else:
+        if lens[rank] > 0:
+            dist.send(packed, 0)
+        out_len = torch.zeros(1, dtype=torch.int64, device=comm_dev)
+    dist.broadcast(out_len, 0)
+    ln = int(out_len.item())
+    res = torch.zeros(2 * ln, dtype=torch.int32, device=comm_dev)
+    if rank == 0:
+        res = torch.from_numpy(np.concatenate([ai, bj]).astype(np.int32)).to(comm_dev)
+    dist.broadcast(res, 0)
+    h = res.cpu().numpy()
+    if eng is not None and keep_engine is None:
+        eng.close()
+    return Result(score, h[:ln].copy(), h[ln:].copy())

@@ -124,3 +124,19 @@ def load_golden(name):
 
 def b64d(s):
     return base64.b64decode(s)
+
+
+def block_codes(a, b, r0, r1, c0, c1, top, left):
+    """As block(), also returning the (r1-r0) x (c1-c0) matrix of destination-indexed winner codes."""
+    a, b = seq(a), seq(b)
+    top = np.ascontiguousarray(top, np.int32)
+    left = np.ascontiguousarray(left, np.int32)
+    bottom = np.zeros_like(top)
+    right = np.zeros_like(left)
+    codes = np.zeros((r1 - r0, c1 - c0), np.uint8)
+    P3 = C.c_void_p * 3
+    mk = lambda arr: P3(*[arr[k].ctypes.data for k in range(3)])
+    rc = lib().psa_oracle_block_codes(_p(a), _p(b), _i64(r0), _i64(r1), _i64(c0), _i64(c1), mk(top), mk(left),
+                                      mk(bottom), mk(right), _p(codes))
+    assert rc == 0
+    return bottom, right, codes
