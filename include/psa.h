@@ -72,6 +72,15 @@ int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
 int psa_score_batch(const uint8_t* seqs, const int64_t* offsets, int64_t nseqs,
                     const int32_t* pairs, int64_t npairs, int32_t* scores_out);
 
+/* Same with everything RESIDENT in device memory (the form a serving loop and bench use):
+ * seqs_dev/offsets_dev/pairs_dev as above, scores_dev receives npairs int32, counter_dev is a
+ * 256-byte device scratch the library zeroes (its work counter).  max_len_b = the longest second
+ * sequence among the pairs (sizes the per-wavefront LDS row buffer), at most 1024: longer pairs
+ * go through psa_score.  Asynchronous on `stream`. */
+int psa_score_batch_dev(const uint8_t* seqs_dev, const int64_t* offsets_dev, const int32_t* pairs_dev,
+                        int64_t npairs, int max_len_b, int32_t* scores_dev, unsigned* counter_dev,
+                        void* stream);
+
 /* The five stdout lines of the reference (simple.cpp:312-313, output_alignement 43-70) for a
  * result; returned buffer is released with psa_free(), *out_len is its length in bytes. */
 char* psa_format_result(int32_t score, const uint8_t* a, const uint8_t* b, const int32_t* ai,

@@ -22,6 +22,7 @@ from .binding import (  # noqa: F401
     read_fasta,
     run,
     score,
+    score_batch,
     set_device,
     synth_protein,
 )

@@ -35,6 +35,8 @@ _SIGNATURES = {
                             C.POINTER(C.c_void_p), _i64p]),
     "psa_score": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, C.c_int, _i32p, _i32p]),
     "psa_score_batch": (C.c_int, [C.c_void_p, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p]),
+    "psa_score_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
     "psa_format_result": (C.c_void_p, [_i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64, _i64p]),
     "psa_finish_alignment": (C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64p]),
     "psa_stripe_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _i64, C.c_void_p, _i64, _i64, _i64,
@@ -133,6 +135,19 @@ def score(a, b, p=1, triple=False):
     t = (_i32 * 3)()
     _check(lib().psa_score(_ptr(a), a.size, _ptr(b), b.size, int(p), C.byref(s), t))
     return (s.value, tuple(t)) if triple else s.value
+
+
+def score_batch(seqs, pairs):
+    """Scores of many independent pairs (psa_score_batch).  seqs: list of byte strings / uint8 arrays;
+    pairs: iterable of (index of A, index of B).  Returns an int32 numpy array."""
+    arrs = [_seq(x) for x in seqs]
+    offsets = np.zeros(len(arrs) + 1, np.int64)
+    offsets[1:] = np.cumsum([x.size for x in arrs])
+    flat = np.concatenate(arrs) if arrs and offsets[-1] else np.zeros(1, np.uint8)
+    pr = np.ascontiguousarray(np.asarray(list(pairs), dtype=np.int32).reshape(-1, 2))
+    out = np.zeros(pr.shape[0], np.int32)
+    _check(lib().psa_score_batch(_ptr(flat), _ptr(offsets), len(arrs), _ptr(pr), pr.shape[0], _ptr(out)))
+    return out
 
 
 def format_result(res, a, b):

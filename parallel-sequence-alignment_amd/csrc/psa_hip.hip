@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "psa_fill_v2.hip.h"
+#include "psa_batch.hip.h"
 
 namespace {
 
@@ -486,8 +487,77 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, i
 
 int psa_score_batch(const uint8_t* seqs, const int64_t* offsets, int64_t nseqs, const int32_t* pairs,
                     int64_t npairs, int32_t* scores_out) {
-    (void)seqs; (void)offsets; (void)nseqs; (void)pairs; (void)npairs; (void)scores_out;
-    return fail(PSA_E_STATE, "psa_score_batch: not built yet");
+    if (npairs < 0 || nseqs < 0 || (npairs && (!seqs || !offsets || !pairs || !scores_out)))
+        return fail(PSA_E_ARG, "psa_score_batch: bad argument");
+    if (npairs == 0) return PSA_OK;
+    if (int rc = need_device()) return rc;
+    // pairs whose B exceeds the LDS row buffer go through the single-pair path
+    std::vector<int64_t> big;
+    for (int64_t k = 0; k < npairs; ++k) {
+        const int32_t sa = pairs[2 * k], sb = pairs[2 * k + 1];
+        if (sa < 0 || sb < 0 || sa >= nseqs || sb >= nseqs) return fail(PSA_E_ARG, "psa_score_batch: pair %lld names a missing sequence", (long long)k);
+        if (offsets[sb + 1] - offsets[sb] > psa::kBatchMaxLen) big.push_back(k);
+    }
+    const size_t total = (size_t)offsets[nseqs];
+    uint8_t* d_seqs = nullptr; int64_t* d_off = nullptr; int32_t* d_pairs = nullptr; int32_t* d_scores = nullptr;
+    unsigned* d_ctr = nullptr;
+    int rc = PSA_OK;
+    auto cleanup = [&]() { hipFree(d_seqs); hipFree(d_off); hipFree(d_pairs); hipFree(d_scores); hipFree(d_ctr); };
+#define B_TRY(expr)                                                                                          \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) { cleanup(); return fail(PSA_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+    } while (0)
+    B_TRY(hipMalloc(&d_seqs, total + 16));
+    B_TRY(hipMalloc(&d_off, sizeof(int64_t) * (size_t)(nseqs + 1)));
+    B_TRY(hipMalloc(&d_pairs, sizeof(int32_t) * 2 * (size_t)npairs));
+    B_TRY(hipMalloc(&d_scores, sizeof(int32_t) * (size_t)npairs));
+    B_TRY(hipMalloc(&d_ctr, 256));
+    B_TRY(hipMemcpy(d_seqs, seqs, total, hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(d_off, offsets, sizeof(int64_t) * (size_t)(nseqs + 1), hipMemcpyHostToDevice));
+    B_TRY(hipMemcpy(d_pairs, pairs, sizeof(int32_t) * 2 * (size_t)npairs, hipMemcpyHostToDevice));
+    int max_b = 0;
+    for (int64_t k = 0; k < npairs; ++k) {
+        const int64_t lb = offsets[pairs[2 * k + 1] + 1] - offsets[pairs[2 * k + 1]];
+        if (lb <= psa::kBatchMaxLen) max_b = std::max(max_b, (int)lb);
+    }
+    rc = psa_score_batch_dev(d_seqs, d_off, d_pairs, npairs, max_b, d_scores, d_ctr, nullptr);
+    if (rc == PSA_OK) B_TRY(hipMemcpy(scores_out, d_scores, sizeof(int32_t) * (size_t)npairs, hipMemcpyDeviceToHost));
+#undef B_TRY
+    cleanup();
+    if (rc != PSA_OK) return rc;
+    for (int64_t k : big) {
+        const int32_t sa = pairs[2 * k], sb = pairs[2 * k + 1];
+        rc = psa_score(seqs + offsets[sa], offsets[sa + 1] - offsets[sa], seqs + offsets[sb], offsets[sb + 1] - offsets[sb], 1,
+                       &scores_out[k], nullptr);
+        if (rc != PSA_OK) return rc;
+    }
+    return PSA_OK;
+}
+
+int psa_score_batch_dev(const uint8_t* seqs_dev, const int64_t* offsets_dev, const int32_t* pairs_dev, int64_t npairs,
+                        int max_len_b, int32_t* scores_dev, unsigned* counter_dev, void* stream) {
+    if (npairs <= 0) return PSA_OK;
+    if (max_len_b < 0 || max_len_b > psa::kBatchMaxLen)
+        return fail(PSA_E_ARG, "psa_score_batch_dev: max_len_b must be in [0, %d]", psa::kBatchMaxLen);
+    if (!seqs_dev || !offsets_dev || !pairs_dev || !scores_dev || !counter_dev)
+        return fail(PSA_E_ARG, "psa_score_batch_dev: null argument");
+    if (int rc = need_device()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(counter_dev, 0, 256, st));
+    psa::BatchArgs ba;
+    ba.seqs = seqs_dev; ba.offsets = offsets_dev; ba.pairs = pairs_dev; ba.npairs = npairs; ba.scores = scores_dev;
+    ba.next_pair = counter_dev;
+    ba.max_b = std::max(64, ((max_len_b + 63) / 64) * 64);
+    const size_t lds_bytes = (size_t)psa::kBatchWaves * psa::batch_wave_bytes(ba.max_b);
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int64_t want = (npairs + psa::kBatchWaves - 1) / psa::kBatchWaves;
+    const unsigned grid = (unsigned)std::min<int64_t>(want, (int64_t)cus * 8);
+    hipLaunchKernelGGL(psa::batch_score_kernel, dim3(grid), dim3(psa::kBatchWaves * 64), lds_bytes, st, ba);
+    HIP_TRY(hipGetLastError());
+    return PSA_OK;
 }
 
 // simple.cpp:312 + output_alignement (simple.cpp:43-70); both Length lines print al_A's size.

@@ -118,3 +118,22 @@ def test_cli_byte_exact(golden_dir):
     assert b"Error opening file: sequences/nope.fasta" in r.stderr
     r = subprocess.run([exe, "only_one_arg"], cwd=golden_dir, capture_output=True, timeout=120)
     assert r.returncode == 1 and b"Usage:" in r.stderr and r.stdout == b""
+
+
+def test_batch_scores_match_oracle():
+    rng = np.random.default_rng(23)
+    seqs = []
+    for ln in [0, 1, 2, 63, 64, 65, 100, 127, 128, 129, 200, 255, 256, 300, 511, 512, 513, 700, 1024, 1100]:
+        alpha = [2, 4, 20][ln % 3]
+        seqs.append(rng.integers(65, 65 + alpha, ln).astype(np.uint8))
+    pairs = [(i, j) for i in range(len(seqs)) for j in range(len(seqs))]
+    got = psa_amd.score_batch(seqs, pairs)
+    for (i, j), g in zip(pairs, got):
+        assert g == O.score(seqs[i], seqs[j]), (len(seqs[i]), len(seqs[j]))
+    # many equal-length pairs (the shape of BASELINE config 5)
+    prot = [psa_amd.synth_protein(0xC0000000 + k, 512) for k in range(64)]
+    pairs = [(i, j) for i in range(64) for j in range(64)]
+    got = psa_amd.score_batch(prot, pairs)
+    for idx in range(0, len(pairs), 37):
+        i, j = pairs[idx]
+        assert got[idx] == O.score(prot[i], prot[j])
