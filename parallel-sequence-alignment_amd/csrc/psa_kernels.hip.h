@@ -247,14 +247,23 @@ __global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
     __shared__ uint4 tile[kTbSlots][3][64];
     __shared__ long long slot_tile[kTbSlots];
     const int lane = threadIdx.x;
-    int64_t i = p.state[0], j = p.state[1];
-    int k = (int)p.state[2];
+    // the walk state is wave-uniform: keep it in SGPRs so that its arithmetic and branches are scalar
+    auto uni64 = [](int64_t x) -> int64_t {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)x >> 32));
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
+    int64_t i = uni64(p.state[0]), j = uni64(p.state[1]);
+    int k = __builtin_amdgcn_readfirstlane((int)p.state[2]);
     int64_t len = 0, done = 0, err = 0;
     const int64_t c0 = p.c0;
     const int64_t Q = p.Q;
     if (lane < kTbSlots) slot_tile[lane] = -1;
     __syncthreads();
     int victim = 0;
+    long long n_iter = 0, n_miss = 0, n_run = 0;
+    long long cur_T = -1;
+    int cur_slot = -1;
     const uint4* codes4 = (const uint4*)p.codes;
 
     auto lookup = [&](long long T) -> int {
@@ -265,6 +274,7 @@ __global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
 
     for (;;) {
         if (i == 0 || j == 0) { done = 1; break; }
+        ++n_iter;
         const int64_t pi = i - (k != 2), pj = j - (k != 3);
         if (c0 > 0 && pj <= c0) break;  // predecessor belongs to the stripe on the left
         int w;
@@ -278,50 +288,39 @@ __global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
             const int64_t t = (pj - c0 - 1) + lp;
             const int64_t q = t >> 6;
             const long long T = strip * Q + q;
-            int slot = lookup(T);
+            int slot = cur_slot;
+            if (T != cur_T) slot = lookup(T);
             if (slot < 0) {
-                // fetch T and the tiles a diagonal continuation would visit next
-                long long ids[kTbBatch];
+                ++n_miss;
+                // fetch T and the tiles a diagonal continuation would visit next: LDS-DMA, one
+                // 1-KB instruction per aggregate and tile, all in flight together, one wait
                 int64_t cpi = pi, cpj = pj;
-#pragma unroll
                 for (int b = 0; b < kTbBatch; ++b) {
-                    ids[b] = -1;
-                    if (cpi >= 1 && cpj >= c0 + 1) {
-                        const int64_t bs = (cpi - 1) >> 6;
-                        const int bl = (int)((cpi - 1) & 63);
-                        const int64_t bt = (cpj - c0 - 1) + bl;
-                        const int64_t bq = bt >> 6;
-                        const long long Tb = bs * Q + bq;
-                        bool dup = lookup(Tb) >= 0;
+                    if (cpi < 1 || cpj < c0 + 1) break;
+                    const int64_t bs = (cpi - 1) >> 6;
+                    const int bl = (int)((cpi - 1) & 63);
+                    const int64_t bt = (cpj - c0 - 1) + bl;
+                    const int64_t bq = bt >> 6;
+                    const long long Tb = bs * Q + bq;
+                    if (lookup(Tb) < 0) {
 #pragma unroll
-                        for (int e = 0; e < b; ++e) dup = dup || ids[e] == Tb;
-                        if (!dup) ids[b] = Tb;
-                        const int64_t s1 = ((bt - (bq << 6)) >> 1) + 1, s2 = bl + 1;
-                        const int64_t sdiag = s1 < s2 ? s1 : s2;
-                        cpi -= sdiag; cpj -= sdiag;
-                    }
-                }
-                uint4 v[kTbBatch][3];
-#pragma unroll
-                for (int b = 0; b < kTbBatch; ++b) {
-                    if (ids[b] >= 0) {
-#pragma unroll
-                        for (int kind = 0; kind < 3; ++kind) v[b][kind] = codes4[(ids[b] * 3 + kind) * 64 + lane];
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int b = 0; b < kTbBatch; ++b) {
-                    if (ids[b] >= 0) {
-#pragma unroll
-                        for (int kind = 0; kind < 3; ++kind) tile[victim][kind][lane] = v[b][kind];
-                        if (lane == 0) slot_tile[victim] = ids[b];
+                        for (int kind = 0; kind < 3; ++kind)
+                            __builtin_amdgcn_global_load_lds(
+                                (const __attribute__((address_space(1))) void*)(codes4 + (Tb * 3 + kind) * 64 + lane),
+                                (__attribute__((address_space(3))) void*)&tile[victim][kind][0], 16, 0, 0);
+                        if (lane == 0) slot_tile[victim] = Tb;
                         victim = (victim + 1) & (kTbSlots - 1);
                     }
+                    const int64_t s1 = ((bt - (bq << 6)) >> 1) + 1, s2 = bl + 1;
+                    const int64_t sdiag = s1 < s2 ? s1 : s2;
+                    cpi -= sdiag; cpj -= sdiag;
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 slot = lookup(T);
             }
+            cur_T = T;
+            cur_slot = slot;
             if (k == 1) {
                 // diagonal run inside this tile: lane l' looks at cell (pi - d, pj - d), d = lp - l'
                 const int d = lp - lane;
@@ -344,11 +343,12 @@ __global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
                         p.out_bj[len + d] = (int32_t)(pj - d);
                     }
                     len += r; i -= r; j -= r;
+                    ++n_run;
                     continue;
                 }
             }
             const uint32_t* wp = (const uint32_t*)&tile[slot][k - 1][lp];
-            const uint32_t word = wp[(t & 63) >> 4];
+            const uint32_t word = __builtin_amdgcn_readfirstlane(wp[(t & 63) >> 4]);
             const unsigned pair = (word >> (2 * (15 - (int)(t & 15)))) & 3u;
             w = (pair & 2u) ? 1 : ((pair & 1u) ? 2 : 3);
         }
@@ -362,6 +362,7 @@ __global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
     }
     if (lane == 0) {
         p.state[0] = i; p.state[1] = j; p.state[2] = k; p.state[3] = done; p.state[4] = len; p.state[5] = err;
+        p.state[6] = (n_iter << 32) | n_run; p.state[7] = n_miss;
     }
 }
 
