@@ -21,6 +21,11 @@
 
 namespace psa {
 
+#ifndef PSA_GDIST
+#define PSA_GDIST 2
+#endif
+constexpr int kGDist = PSA_GDIST;  // granule requests run this many blocks ahead (1, 2 or 4)
+constexpr int kFrontWord = 32;  // control block: [0] ticket, [1] abort flag, [32] front (own cache line)
 constexpr int kNW = 4;         // strips (wavefronts) per workgroup
 constexpr int kRing = 256;     // LDS ring slots per strip boundary (8 bytes each)
 constexpr int kBlk = 16;       // steps per block
@@ -175,7 +180,7 @@ __device__ __forceinline__ void lds_post(int* p, int v) {
 
 __device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* abort_flag, unsigned limit = 1u << 25) {
     __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 63u) == 0) {
+    if ((++spins & 1023u) == 0) {   // rarely: hundreds of waiting waves share this one address
         const unsigned ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (ab || spins > limit) {
             __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -192,6 +197,7 @@ struct StripCtx {
     StripState S;
     int lane;
     int wv;                 // (u) wave inside the workgroup
+    int wg;                 // (u) workgroup's ticket = its place in the chain of this launch
     int W, nblocks;         // (u)
     bool from_lds, to_lds, to_hbm, top_analytic;  // (u)
     bool row_ok;
@@ -209,9 +215,10 @@ struct StripCtx {
     int* cons_post;         // lane 0 of an LDS consumer: its cons counter; else a dump word
     const u64* gin;
     u64* gout;
+    u64* gdump;             // 64 granules behind the ring that nobody reads (one per lane)
     u64 tag_in, tag_out;
     int carryD;
-    u64 gq[4];              // granules requested for blocks 0..3 of the next superblock (wave 0 path)
+    u64 gq[kGDist];         // granules requested kGDist blocks ahead (wave 0 path), by block index mod kGDist
     unsigned gq_valid;      // (u) bit j: gq[j] holds a request
     unsigned wait_in, wait_room;  // (u) spin iterations, for the profile only
 #ifdef PSA_EXP_TIMING
@@ -239,7 +246,7 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     // ---- 1. lane 0's inputs for columns t0..t0+15: ring slots t0+64..t0+79 ----
     const int slot0 = (t0 + 64) & (kRing - 1);
     if (from_lds) {
-        if (MODE == kFast || MODE == kHead || t0 < W) {
+        if (MODE == kFast || MODE == kHead || t0 < W) {   // (no run-time condition in the steady state)
             // slots t0+64..t0+79 are complete once the producer has finished step t0+78; it stops at nblocks*16
             const int need = min(t0 + 80, c.nblocks * kBlk);
             if (c.prod_seen < need) {
@@ -251,6 +258,8 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
             }
         }
     } else if (MODE == kFast || MODE == kHead || t0 < W) {
+        // (unconditional in the steady state, also in its blocks past the last column, where col_ok is
+        // false for every lane: a request that may be skipped would spoil the counted waits)
         // wave 0: fetch (D, V) of the row above for 16 columns into lanes 0..15, write the ring itself
         int gD, gV;
         const int col = t0 + lane;
@@ -262,41 +271,58 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
             gD = max3i(t1, t2, t3) + (int)(3 * j);
             gV = max3i(t1, t2, t3 + 2) + (int)(3 * j);
         } else {
-            // granules of this block were requested one superblock (four blocks) ago; if the strip above
-            // had not published them yet, poll until it has
+            // granules of this block were requested one block ago (a request any further ahead only
+            // makes the strip settle that much further behind the one above: it runs ahead until its
+            // requests start to miss); if the strip above had not published them yet, poll until it has
             unsigned spins = 0;
-            u64 g = c.gq[JB];
-            bool have = (c.gq_valid >> JB) & 1;
-#ifdef PSA_EXP_HANDOFF
-            const u64 tlook = wall_clock64();
-            const bool pre_ok = have;
-#endif
-            for (;;) {
-                if (!have) g = col_ok ? load_granule(c.gin + col) : (c.tag_in << 32);
-                have = false;
-                const bool ok = !col_ok || (g >> 32) == c.tag_in;
-                if (__all(ok)) break;
-                if (spin_expired(spins, p.abort_flag, 1u << 22)) return false;
+            u64 g = c.gq[JB % kGDist];
+            if (MODE == kFast && IN == kInHbm) {
+                // steady state: the request is always there.  No load on the straight path, so the wait
+                // for g is a counted one; a load that MAY have been issued just before would turn it
+                // into a wait for everything in flight (table words, code stores).
+                bool ok = !col_ok || (g >> 32) == c.tag_in;
+                if (!__all(ok)) {
+                    do {
+                        if (spin_expired(spins, p.abort_flag, 1u << 22)) return false;
+                        g = col_ok ? load_granule(c.gin + col) : (c.tag_in << 32);
+                        ok = !col_ok || (g >> 32) == c.tag_in;
+                    } while (!__all(ok));
+                }
+            } else {
+                bool have = (c.gq_valid >> (JB % kGDist)) & 1;
+                for (;;) {
+                    if (!have) g = col_ok ? load_granule(c.gin + col) : (c.tag_in << 32);
+                    have = false;
+                    const bool ok = !col_ok || (g >> 32) == c.tag_in;
+                    if (__all(ok)) break;
+                    if (spin_expired(spins, p.abort_flag, 1u << 22)) return false;
+                }
             }
             c.wait_in += spins;
-#ifdef PSA_EXP_HANDOFF
-            if (p.prof && lane == 0) {
-                u64* dbg = p.prof + 4 * (((p.r1 - p.r0) + 63) >> 6) + ((c.sg * (u64)c.nblocks + (t0 >> 4)) * 4);
-                dbg[0] = tlook; dbg[1] = wall_clock64(); dbg[2] = ((u64)pre_ok << 32) | spins;
-            }
-#endif
             gD = (int)((unsigned)g >> 2);
             gV = gD + (int)((unsigned)g & 3u);
-            // request the same block of the next superblock
-            const int ncol = col + 64;
-            const bool nvalid = (t0 + 64 < W);
-            if (nvalid) c.gq[JB] = (lane < kBlk && ncol < W) ? load_granule(c.gin + ncol) : (c.tag_in << 32);
-            c.gq_valid = (c.gq_valid & ~(1u << JB)) | ((unsigned)nvalid << JB);
+            // request the block kGDist blocks ahead
+            if (MODE == kFast && IN == kInHbm) {
+                // unconditional and unmasked (lanes 16..63 repeat lanes 0..15, columns past the end are
+                // clamped and never looked at): a load that may be skipped would force every later wait
+                // on the vector-memory counter to be a wait for zero
+                c.gq[JB % kGDist] = load_granule(c.gin + min(t0 + kGDist * kBlk + (lane & (kBlk - 1)), W - 1));
+                c.gq_valid |= 1u << (JB % kGDist);
+            } else {
+                const int ncol = col + kGDist * kBlk;
+                const bool nvalid = (t0 + kGDist * kBlk < W);
+                if (nvalid) c.gq[JB % kGDist] = (lane < kBlk && ncol < W) ? load_granule(c.gin + ncol) : (c.tag_in << 32);
+                c.gq_valid = (c.gq_valid & ~(1u << (JB % kGDist))) | ((unsigned)nvalid << (JB % kGDist));
+            }
         }
         // slot(col) = (D of col-1, V of col)
         const int Dm1 = shift_down1(c.carryD, gD);
         c.carryD = __builtin_amdgcn_readlane(gD, kBlk - 1);
         if (lane < kBlk) c.my_ring[slot0 + lane] = make_int2(Dm1, gV);
+    }
+    if (MODE == kHead && JB == 0 && IN != kInLds) {
+        // first block of wave 0 (t0 = 0), its input has arrived: move the front (see the kernel's prologue)
+        if (lane == 0) __hip_atomic_fetch_max(p.ticket + kFrontWord, (unsigned)c.wg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int4* rp = (const int4*)(c.my_ring + slot0);
     int4 pre[8];
@@ -307,34 +333,46 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     int* pa = c.out_base + (c.out_wrap ? ((2 * t0) & (c.out_wrap - 1)) : 0);
     int* pb = c.out_base + (c.out_wrap ? ((2 * (t0 + kBlk)) & (c.out_wrap - 1)) : 0);
 
+    // A strip that publishes through HBM reads back what lane 63 dropped into the staging slots
+    // during the PREVIOUS block (columns t0-80 .. t0-65, complete since step t0-2) and stores the
+    // granules a few steps into this block: the LDS round trip hides behind those steps.
+    constexpr int kFlushAt = 4;
+    constexpr bool flush_always = (MODE == kFast && OUT == kOutHbm);   // no branch, no mask (see the request above)
+    // (steady state: lanes 16..63 repeat lanes 0..15 -- same address, same data -- instead of being masked off)
+    const int fcol = t0 - 80 + (flush_always ? (lane & (kBlk - 1)) : lane);
+    const bool flush = to_hbm && t0 >= 80 && t0 - 80 < W;
+    int fv = 0, fd = 0;
+    if (flush_always || (flush && lane < kBlk && fcol < W)) {
+        // staging slot of column c is c + 64 (numbered like the ring): V in .y of the slot, D in .x of the next
+        fv = lds.stage[c.wv][(fcol + 64) & 31].y;
+        fd = lds.stage[c.wv][(fcol + 65) & 31].x;
+    }
+    PSA_COMPILER_BARRIER();
+
     // ---- 2. the sixteen steps ----
 #pragma unroll
-    for (int k = 0; k < kBlk; ++k)
+    for (int k = 0; k < kFlushAt; ++k)
         step16<CODES, MODE>(k, c.S, pre[k >> 1], (k < 8) ? mlo : mhi, pa, pb, t0 + k, lane, W, c.row_ok);
-
-    // ---- 3. publish progress / flush granules ----
-    if (OUT == kAny || OUT == kOutLds) lds_post(c.prod_post, t0 + kBlk);
-    if (to_hbm) {
-        // columns t0-64 .. t0-49 were completed by the end of this block (lane 63, step = column + 63)
-        const int cb = t0 - 64;
-        if (cb >= 0 && cb < W) {
-            const int col = cb + lane;
-            if (lane < kBlk && col < W) {
-                // staging slot of column c is c + 64 (numbered like the ring): V in .y of the slot, D in .x of the next
-                const int vs = lds.stage[c.wv][(col + 64) & 31].y;
-                const int ds = lds.stage[c.wv][(col + 65) & 31].x;
-                store_granule(c.gout + col, (c.tag_out << 32) | ((unsigned)ds << 2) | (unsigned)(vs - ds));
-            }
+    if (OUT == kAny || OUT == kOutHbm) {
+        const u64 gran = (c.tag_out << 32) | ((unsigned)fd << 2) | (unsigned)(fv - fd);
+        if (flush_always) {
+            // every lane stores; in the few blocks per strip whose columns would be negative or past
+            // the end the stores go to dump slots.  Not more often than that: a few
+            // lines written by every strip of the device at every block are a hot spot that slows
+            // every other access to their memory channel.
+            store_granule((fcol >= 0 && fcol < W) ? c.gout + fcol : c.gdump, gran);
             PSA_COMPILER_BARRIER();
-#ifdef PSA_EXP_HANDOFF
-            if (p.prof && lane == 0) {
-                // consumer strip sg+1, its block cb/16
-                u64* dbg = p.prof + 4 * (((p.r1 - p.r0) + 63) >> 6) + (((c.sg + 1) * (u64)c.nblocks + (cb >> 4)) * 4);
-                dbg[3] = wall_clock64();
-            }
-#endif
+        } else if (flush) {
+            if (lane < kBlk && fcol < W) store_granule(c.gout + fcol, gran);
+            PSA_COMPILER_BARRIER();
         }
     }
+#pragma unroll
+    for (int k = kFlushAt; k < kBlk; ++k)
+        step16<CODES, MODE>(k, c.S, pre[k >> 1], (k < 8) ? mlo : mhi, pa, pb, t0 + k, lane, W, c.row_ok);
+
+    // ---- 3. publish progress ----
+    if (OUT == kAny || OUT == kOutLds) lds_post(c.prod_post, t0 + kBlk);
     return true;
 }
 
@@ -406,7 +444,10 @@ __device__ __forceinline__ bool run_steady_out(StripCtx<CODES>& c, FillLds& lds,
 }
 
 template <bool CODES>
-__global__ __launch_bounds__(kNW * 64) void fill_strips_v2(FillArgs2 q) {
+// One workgroup per CU, one wavefront per SIMD: every strip is a link of one dependency chain, so
+// two workgroups sharing a CU (each at half speed) would hold up every strip behind them.  The
+// occupancy attribute makes the register budget 512 per wave and keeps a second workgroup out.
+__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void fill_strips_v2(FillArgs2 q) {
     __shared__ FillLds lds;
     __shared__ unsigned wg_ticket;
     const FillArgs& p = q.base;
@@ -476,8 +517,9 @@ __global__ __launch_bounds__(kNW * 64) void fill_strips_v2(FillArgs2 q) {
     c.tag_out = (u64)(sg + 1);
     c.gin = p.ring + (size_t)(((sg - 1) / kNW) & 1) * p.Wpad;  // bottom row of strip sg-1
     c.gout = p.ring + (size_t)((sg / kNW) & 1) * p.Wpad;
+    c.gdump = p.ring + 2 * (size_t)p.Wpad + lane;
     c.carryD = D_up;          // D of column t0-1 of the row above (wave 0 path)
-    c.gq[0] = c.gq[1] = c.gq[2] = c.gq[3] = 0;
+    for (int j = 0; j < kGDist; ++j) c.gq[j] = 0;
     c.gq_valid = 0;
     c.wait_in = c.wait_room = 0;
 #ifdef PSA_EXP_TIMING
@@ -485,6 +527,31 @@ __global__ __launch_bounds__(kNW * 64) void fill_strips_v2(FillArgs2 q) {
 #endif
 
     const int nblocks = c.nblocks = p.Q * (64 / kBlk);
+    // A workgroup far down the chain waits for a long time before its first granule arrives.
+    // Hundreds of them polling -- even slowly, if it is the same few cache lines -- slow the loads of
+    // the strips that do run.  So a waiting workgroup first sleeps on the chain's "front": the number
+    // of workgroups that have received their first input (kFrontWord of the control block, raised
+    // by wave 0 of each workgroup in its very first block).  The sleep between two looks grows with
+    // the distance to the front, so a workgroup looks a handful of times in all.  Once the
+    // workgroup two above has begun, this one's input is some tens of microseconds away and it
+    // goes on to poll its own granules finely.
+    c.wg = __builtin_amdgcn_readfirstlane(wg_ticket);
+    if (wv == 0 && c.wg >= 2 && W >= 128) {
+        unsigned spins = 0;
+        for (;;) {
+            const unsigned f = __builtin_amdgcn_readfirstlane(
+                __hip_atomic_load(p.ticket + kFrontWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const int d = (int)c.wg - 1 - (int)f;   // workgroup wg-2 has begun once f >= (wg-2)+1
+            if (d <= 0) break;
+            const int naps = min(2 * d, 256);       // 3.4 us each; a workgroup step is 15-30 us
+            for (int j = 0; j < naps; ++j) __builtin_amdgcn_s_sleep(127);
+            const unsigned ab = __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ab || ++spins > (1u << 16)) {
+                __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+    }
     if (p.prof && lane == 0) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -499,7 +566,13 @@ __global__ __launch_bounds__(kNW * 64) void fill_strips_v2(FillArgs2 q) {
     // Wide stripes: head + steady state compiled per role, then a tail that captures the right
     // boundary.  Narrow stripes (W < 128): one generic, fully predicated loop.
     if (W >= 128) {
-        const int fast_hi = (W - 1) / 64;  // superblock sb is steady iff 64 sb + 64 <= W - 1
+        // Superblock sb is steady iff 64 sb + 64 <= W - 1.  The superblocks after that, in which the
+        // lanes leave on the right, need the slower capturing steps only where somebody wants the
+        // values at column W-1: a right boundary was asked for, or this strip holds the last row.
+        // Everywhere else they run in the steady-state code too -- the time a strip needs for its
+        // last ~100 steps is what separates its end from the end of the strip above, 1023 times over.
+        const bool capture = p.right != nullptr || (row_base < p.n && p.n <= row_base + 64);
+        const int fast_hi = capture ? (W - 1) / 64 : p.Q;
         bool ok;
         if (c.from_lds) ok = run_steady_out<CODES, kInLds>(c, lds, p, 0, fast_hi);
         else if (c.top_analytic) ok = run_steady_out<CODES, kInTop>(c, lds, p, 0, fast_hi);
@@ -533,7 +606,7 @@ __global__ __launch_bounds__(kNW * 64) void fill_strips_v2(FillArgs2 q) {
     }
     // ---- trailing granule group (columns whose flush block lies beyond the last block) ----
     if (c.to_hbm) {
-        for (int cb = nblocks * kBlk - 64; cb < W; cb += kBlk) {
+        for (int cb = nblocks * kBlk - 80; cb < W; cb += kBlk) {
             if (cb < 0) continue;
             PSA_COMPILER_BARRIER();
             const int col = cb + lane;

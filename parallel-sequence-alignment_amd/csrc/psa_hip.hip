@@ -173,7 +173,7 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
     CREATE_TRY(hipMalloc(&s->b_dev, (size_t)s->W));
     CREATE_TRY(hipMemcpy(s->a_dev, a, (size_t)n, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(s->b_dev, b + c0, (size_t)s->W, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMalloc(&s->ring, sizeof(psa::u64) * 2 * (size_t)s->Wpad));
+    CREATE_TRY(hipMalloc(&s->ring, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64)));  // + dump slots, see fill_strips_v2
     CREATE_TRY(hipMalloc(&s->small, 64));
     CREATE_TRY(hipMalloc(&s->ctrl, kCtrlBytes));
     if (flags & PSA_F_TRACEBACK) {
@@ -216,7 +216,7 @@ int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* l
         return fail(PSA_E_ARG, "psa_stripe_fill_rows: left boundary must be given exactly when c0 > 0");
     hipStream_t st = (hipStream_t)stream;
     if (r0 == 0) {
-        HIP_TRY(hipMemsetAsync(s->ring, 0, sizeof(psa::u64) * 2 * (size_t)s->Wpad, st));
+        HIP_TRY(hipMemsetAsync(s->ring, 0, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64), st));
         s->corner_cur = 0;
     }
     HIP_TRY(hipMemsetAsync(s->ctrl, 0, kCtrlBytes, st));
