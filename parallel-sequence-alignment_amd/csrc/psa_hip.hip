@@ -182,7 +182,7 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
         s->tb_cap = n + s->W + 2;
         CREATE_TRY(hipMalloc(&s->tb_ai, sizeof(int32_t) * (size_t)s->tb_cap));
         CREATE_TRY(hipMalloc(&s->tb_bj, sizeof(int32_t) * (size_t)s->tb_cap));
-        CREATE_TRY(hipMalloc(&s->tb_state, sizeof(int64_t) * 8));
+        CREATE_TRY(hipMalloc(&s->tb_state, sizeof(int64_t) * 12));
     }
     for (auto& e : s->ev) CREATE_TRY(hipEventCreate(&e));
     s->tab_pitch = psa::kTabPad + (64 * s->Q + 64) / 8 + 8;
@@ -316,7 +316,7 @@ int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io,
         return fail(PSA_E_ARG, "psa_stripe_traceback: bad state (%lld,%lld,%d)", (long long)*i_io, (long long)*j_io, *k_io);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = check_abort(s, st)) return rc;
-    int64_t state[8] = {*i_io, *j_io, *k_io, 0, 0, 0, 0, 0};
+    int64_t state[12] = {*i_io, *j_io, *k_io, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(s->tb_state, state, sizeof state, hipMemcpyHostToDevice, st));
     psa::TraceArgs ta;
     ta.codes = s->codes; ta.c0 = s->c0; ta.W = s->W; ta.Q = s->Q; ta.cap = s->tb_cap;
@@ -324,15 +324,20 @@ int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io,
     HIP_TRY(hipEventRecord(s->ev[2], st));
     {
         const char* force = getenv("PSA_TRACEBACK_KERNEL");
-        if (force && !strcmp(force, "v1")) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
-        else hipLaunchKernelGGL(psa::traceback_v2, dim3(1), dim3(64), 0, st, ta);
+        // the fast kernels keep the walk in 32-bit registers: coordinates and tile ids must fit
+        const bool fits32 = s->n < 0x7fff0000LL && s->c0 + s->W < 0x7fff0000LL &&
+                            ((s->n + 63) / 64) * (int64_t)s->Q < 0x7fff0000LL;
+        if ((force && !strcmp(force, "v1")) || !fits32) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
+        else if (force && !strcmp(force, "v2")) hipLaunchKernelGGL(psa::traceback_v2, dim3(1), dim3(64), 0, st, ta);
+        else hipLaunchKernelGGL(psa::traceback_v3, dim3(1), dim3(64), 0, st, ta);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[3], st));
     s->tb_timed = true;
     HIP_TRY(hipMemcpyAsync(state, s->tb_state, sizeof state, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: len %lld iterations %lld runs %lld misses %lld\n", (long long)state[4], (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)state[7]);
+    if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: len %lld iterations %lld runs/tiles %lld misses %lld\n", (long long)state[4], (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)state[7]);
+    if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld\n", (long long)state[8], (long long)state[9]);
     if (state[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow");
     const int64_t got = state[4];
     if (*len_io + got > cap) return fail(PSA_E_ARG, "psa_stripe_traceback: output capacity %lld too small", (long long)cap);

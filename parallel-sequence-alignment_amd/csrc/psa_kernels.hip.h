@@ -366,4 +366,171 @@ __global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
     }
 }
 
+// ---- traceback, third version: 32-bit scalar state, tile directory in registers, prefetch ----
+// Same walk as traceback_v2 with the per-iteration cost cut down:
+//   * the walk state (i, j, table, output length, tile ids) is 32-bit and wave-uniform (SGPRs);
+//     the host checks that the stripe's coordinates and tile count fit (else traceback_v1 runs);
+//   * the tile directory (which tile sits in which LDS slot, and the issue number of its fetch)
+//     lives in lanes 0..15 of two VGPRs: a lookup is one compare + ballot, no LDS round trip;
+//   * tiles are fetched ahead of the walk along its current diagonal (LDS-DMA, asynchronous);
+//     entering a tile waits only for that tile's fetch: "all but the N most recent vector-memory
+//     operations are complete" with N = 3 x (tiles requested after it);
+//   * in table 1 one ballot pass handles a whole diagonal run AND the non-diagonal step that
+//     ends it (its two bits sit in the word the lane already holds).
+constexpr int kTb3Ahead = 6;
+
+__device__ __forceinline__ void tb_wait_vm(int n_after) {
+    // wait until the fetch that has n_after tile fetches (3 instructions each) behind it is complete
+    if (n_after >= 16) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (n_after >= 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n_after >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n_after >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n_after >= 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(64) void traceback_v3(TraceArgs p) {
+    __shared__ uint4 tile[kTbSlots][3][64];
+    const int lane = threadIdx.x;
+    int i = __builtin_amdgcn_readfirstlane((int)p.state[0]);
+    int j = __builtin_amdgcn_readfirstlane((int)p.state[1]);
+    int k = __builtin_amdgcn_readfirstlane((int)p.state[2]);
+    const int c0 = (int)p.c0;
+    const int Q = p.Q;
+    const int cap = (int)(p.cap < 0x7fffff00 ? p.cap : 0x7fffff00);
+    int len = 0, done = 0, err = 0;
+    int my_tile = -1, my_seq = 0;          // lanes 0..15: directory of the LDS slots
+    int victim = 0, seq_issued = 0, seq_done = 0;
+    int cur_T = -1, cur_slot = 0;
+    int cpi = 0, ahead = 0;                // prefetch cursor: a row on the walk's diagonal, tiles ahead
+    int n_iter = 0, n_miss = 0, n_tiles = 0;
+    const uint4* codes4 = (const uint4*)p.codes;
+    const long long tc0 = (long long)__builtin_readcyclecounter(), tw0 = (long long)wall_clock64();
+
+    auto lookup = [&](int T) -> int {
+        const unsigned long long m = __ballot(my_tile == T);
+        return m ? (int)__builtin_ctzll(m) : -1;
+    };
+    auto issue = [&](int T) {
+#pragma unroll
+        for (int kind = 0; kind < 3; ++kind)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(codes4 + ((long long)T * 3 + kind) * 64 + lane),
+                (__attribute__((address_space(3))) void*)&tile[victim][kind][0], 16, 0, 0);
+        ++seq_issued;
+        if (lane == victim) { my_tile = T; my_seq = seq_issued; }
+        victim = (victim + 1) & (kTbSlots - 1);
+    };
+
+    for (;;) {
+        if (i == 0 || j == 0) { done = 1; break; }
+        ++n_iter;
+        const int pi = i - (k != 2), pj = j - (k != 3);
+        if (c0 > 0 && pj <= c0) break;  // predecessor belongs to the stripe on the left
+        if (pi == 0 || pj == 0) {
+            int t1, t2, t3;
+            boundary_triple(pi, pj, t1, t2, t3);
+            const int w = winner_plain(t1, t2, t3, k);
+            if (len >= cap) { err = 1; break; }
+            if (lane == 0) {
+                p.out_ai[len] = (w == 2) ? -1 : (i - 1);
+                p.out_bj[len] = (w == 3) ? -1 : (j - 1);
+            }
+            ++len; i = pi; j = pj; k = w;
+            continue;
+        }
+        const int strip = (pi - 1) >> 6;
+        const int lp = (pi - 1) & 63;
+        const int t = (pj - c0 - 1) + lp;
+        const int q = t >> 6;
+        const int T = strip * Q + q;
+        if (T != cur_T) {
+            ++n_tiles;
+            int slot = lookup(T);
+            if (slot < 0) {
+                ++n_miss;
+                slot = victim;
+                issue(T);
+                cpi = pi; ahead = 0;
+            } else {
+                ahead = ahead > 0 ? ahead - 1 : 0;
+                if (cpi > pi) { cpi = pi; ahead = 0; }
+            }
+            // keep the fetches kTb3Ahead tiles ahead of the walk, along its current diagonal
+            const int diag = pi - pj;
+#pragma unroll 1
+            for (int rep = 0; rep < 2 && ahead < kTb3Ahead && cpi >= 1; ++rep) {
+                const int cj = cpi - diag;
+                if (cj < c0 + 1) { cpi = 0; break; }
+                const int bl = (cpi - 1) & 63;
+                const int bt = (cj - c0 - 1) + bl;
+                const int s1 = ((bt & 63) >> 1) + 1, s2 = bl + 1;
+                cpi -= s1 < s2 ? s1 : s2;          // first cell of the next tile on the diagonal
+                const int nj = cpi - diag;
+                if (cpi < 1 || nj < c0 + 1) { cpi = 0; break; }
+                const int nl = (cpi - 1) & 63;
+                const int Tn = ((cpi - 1) >> 6) * Q + (((nj - c0 - 1) + nl) >> 6);
+                if (lookup(Tn) < 0) issue(Tn);
+                ++ahead;
+            }
+            // the tile being entered must have landed
+            const int sq = __builtin_amdgcn_readlane(my_seq, slot);
+            if (sq > seq_done) { tb_wait_vm(seq_issued - sq); seq_done = sq; }
+            __builtin_amdgcn_s_barrier();   // single wave: orders the LDS reads below behind the wait
+            cur_T = T; cur_slot = slot;
+        }
+        const int slot = cur_slot;
+        if (k == 1) {
+            // lane l' looks at cell (pi - d, pj - d), d = lp - l': a run of "table 1 wins" bits from
+            // lane lp downwards is a diagonal run; the first cell without the bit (if it is still
+            // inside this tile and stripe) gives the step that follows the run
+            const int d = lp - lane;
+            const int tt = t - 2 * d;
+            const bool valid = d >= 0 && tt >= (q << 6) && (pj - d) >= c0 + 1;
+            unsigned pair = 0;
+            if (valid) {
+                const uint32_t* wp = (const uint32_t*)&tile[slot][0][lane];
+                pair = (wp[(tt & 63) >> 4] >> (2 * (15 - (tt & 15)))) & 3u;
+            }
+            const unsigned long long mv = __ballot(valid);
+            const unsigned long long m1 = __ballot(valid && (pair & 2u));
+            const unsigned long long m23 = __ballot(valid && (pair & 1u));
+            const unsigned long long upto = (lp == 63) ? ~0ull : ((1ull << (lp + 1)) - 1);
+            const unsigned long long inv = ~m1 & upto;
+            const int lr = inv ? 63 - (int)__builtin_clzll(inv) : -1;   // lane of the first cell that is not a diagonal move
+            const int r = lp - lr;                                       // run length (lp + 1 when the run leaves the tile's rows)
+            const bool has_g = lr >= 0 && ((mv >> lr) & 1ull);
+            const int w = ((m23 >> (lr & 63)) & 1ull) ? 2 : 3;
+            const int cnt = r + (has_g ? 1 : 0);
+            if (len + cnt > cap) { err = 1; break; }
+            if (d >= 0 && d < cnt) {
+                const bool g = (d == r);
+                p.out_ai[len + d] = (g && w == 2) ? -1 : (pi - d);
+                p.out_bj[len + d] = (g && w == 3) ? -1 : (pj - d);
+            }
+            len += cnt;
+            if (has_g) { i = pi - r; j = pj - r; k = w; }
+            else { i -= r; j -= r; }
+            continue;
+        }
+        // tables 2 and 3 (inside a gap): one step
+        const uint32_t* wp = (const uint32_t*)&tile[slot][k - 1][lp];
+        const uint32_t word = __builtin_amdgcn_readfirstlane(wp[(t & 63) >> 4]);
+        const unsigned pair = (word >> (2 * (15 - (t & 15)))) & 3u;
+        const int w = (pair & 2u) ? 1 : ((pair & 1u) ? 2 : 3);
+        if (len >= cap) { err = 1; break; }
+        if (lane == 0) {
+            p.out_ai[len] = (w == 2) ? -1 : (i - 1);
+            p.out_bj[len] = (w == 3) ? -1 : (j - 1);
+        }
+        ++len; i = pi; j = pj; k = w;
+    }
+    if (lane == 0) {
+        p.state[0] = i; p.state[1] = j; p.state[2] = k; p.state[3] = done; p.state[4] = len; p.state[5] = err;
+        p.state[6] = ((long long)n_iter << 32) | (unsigned)n_tiles; p.state[7] = n_miss;
+        p.state[8] = (long long)__builtin_readcyclecounter() - tc0; p.state[9] = (long long)wall_clock64() - tw0;
+    }
+}
+
+
 }  // namespace psa
