@@ -42,7 +42,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(a, b, log2s=15):
+def cpu_baseline(a, b, log2s=16):
     """Oracle's striped multi-thread port (kind "port") on a bounded prefix sample of the workload."""
     import oracle_lib as O
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
@@ -54,6 +54,28 @@ def cpu_baseline(a, b, log2s=15):
             "sample": "prefix %dx%d of the workload pair, fill + codes + traceback, %d threads (oracle/psa_oracle.c "
                       "psa_oracle_align_mt), %.2f s" % (s, s, cores, dt),
             "score": int(sc)}
+
+
+def pmc_traffic(kernel_substr, grid):
+    """HBM bytes per launch of the fill kernel from the committed rocprofv3 --pmc passes (WRITE_SIZE and
+    FETCH_SIZE, one pass each, summarised by tools/rocpd_summary.py into profiles/).  FETCH_SIZE is doubled
+    (gfx950 correction, MI355X_MICROARCH.md, HBM section).  None when the summaries are absent."""
+    import csv
+    tot, src = 0.0, []
+    for name, scale in (("pmc_w_bench_2p16_b.csv", 1024.0), ("pmc_f_bench_2p16_b.csv", 2048.0)):
+        path = os.path.join(ROOT, "profiles", "r1", name)
+        if not os.path.exists(path):
+            return None, None
+        hit = False
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if kernel_substr in row["kernel"] and int(row["grid_size"]) == grid and row["counter"] in ("WRITE_SIZE", "FETCH_SIZE"):
+                    tot += float(row["avg_value"]) * scale
+                    hit = True
+        if not hit:
+            return None, None
+        src.append("profiles/r1/" + name)
+    return tot, src
 
 
 def single_gpu(args):
@@ -99,6 +121,7 @@ def single_gpu(args):
     fill = sum(fill_ms) / len(fill_ms)
     achieved = cells * OPS_PER_CELL_CODES / (fill * 1e-3) / 1e12
     code_bytes = st.code_bytes()
+    traffic, traffic_src = pmc_traffic("fill_strips_v2<true>", 65536) if k == 16 else (None, None)
     out = {
         "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of a 2^%d x 2^%d pair" % (k, k),
         "value": cells / (dt / args.steps) / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
@@ -111,7 +134,8 @@ def single_gpu(args):
                      "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
                      "ops_per_cell": OPS_PER_CELL_CODES, "kernel_ms": fill, "fill_gcups": cells / (fill * 1e-3) / 1e9,
                      "structural_ceiling": min(1.0, cells / ((n + m) * 65536.0)),
-                     "traffic": None,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (separate --pmc passes)",
+                     "traffic_source": traffic_src,
                      "code_stream": {"bytes": code_bytes, "GBps": code_bytes / (fill * 1e-3) / 1e9,
                                      "frac_of_hbm_peak": code_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "traceback_ms": sum(tb_ms) / len(tb_ms),
