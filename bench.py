@@ -6,7 +6,11 @@
 One "step" = one complete alignment of the workload pair: DP fill with packed winner codes
 written to HBM, final pick, traceback walk, prefix fix-up (what run() does in simple.cpp:261-294).
 Inputs are resident in HBM before the timed region.  N = 1: the synthetic 2^16 x 2^16 protein
-pair of BASELINE config 4 on one GPU.  N > 1 (launched by torch.distributed.run, one rank per
+pair of BASELINE config 4 on one GPU.  One pair alone cannot fill the GPU (its anti-diagonal
+dependency chain is n + m steps long whatever the hardware), so the job keeps --in-flight
+(default 3) independent alignments going at a time, each on its own stream with its own code
+buffer; "value" is the job's throughput, "one_pair_alone" the latency of a single alignment, and
+the roofline object is the fill kernel measured alone.  N > 1 (launched by torch.distributed.run, one rank per
 GPU): the same pair cut into N column stripes, stripe g on GPU g, boundary columns streamed
 g -> g+1 with RCCL send/recv in row chunks (strong scaling).  Rank 0 prints ONE JSON line.
 
@@ -33,10 +37,11 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1)")
+    ap.add_argument("--in-flight", type=int, default=3, help="independent alignments in flight (N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
@@ -79,6 +84,8 @@ def pmc_traffic(kernel_substr, grid):
 
 
 def single_gpu(args):
+    import threading
+    import numpy as np
     import torch
     import psa_amd
     torch.cuda.set_device(0)
@@ -89,14 +96,13 @@ def single_gpu(args):
     b = psa_amd.synth_protein(0xB0000000 + k, m)
     a_dev = torch.from_numpy(a).cuda()
     b_dev = torch.from_numpy(b).cuda()
-    stream = torch.cuda.current_stream().cuda_stream
-    st = psa_amd.Stripe(a, b, 0, m, traceback=True)
-    import numpy as np
+    P = max(1, args.in_flight)
+    stripes = [psa_amd.Stripe(a, b, 0, m, traceback=True) for _ in range(P)]
+    streams = [torch.cuda.Stream() for _ in range(P)]
     cap = 2 * (n + m) + 2
-    ai = np.zeros(cap, np.int32)
-    bj = np.zeros(cap, np.int32)
 
-    def step():
+    def one_alignment(st, stream, ai, bj):
+        """run() of the reference for one pair whose residues are already in HBM."""
         st.set_sequences_dev(a_dev.data_ptr(), b_dev.data_ptr(), stream)
         st.fill_rows(0, n, None, None, stream)
         t = st.final(stream)
@@ -105,41 +111,90 @@ def single_gpu(args):
         fa, fb = psa_amd.finish_alignment(ai[:ln], bj[:ln], n, m)
         return sc, len(fa)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(count):
+        """`count` independent alignments, up to P of them in flight: one host thread, stripe object and
+        stream per slot; a slot takes the next alignment as soon as it has finished its last one."""
+        lock = threading.Lock()
+        state = {"next": 0}
+        res, fill_ms, tb_ms = [], [], []
+
+        def worker(slot):
+            st, stream = stripes[slot], streams[slot].cuda_stream
+            ai = np.zeros(cap, np.int32)
+            bj = np.zeros(cap, np.int32)
+            while True:
+                with lock:
+                    if state["next"] >= count:
+                        return
+                    state["next"] += 1
+                r = one_alignment(st, stream, ai, bj)
+                with lock:
+                    res.append(r); fill_ms.append(st.last_fill_ms()); tb_ms.append(st.last_traceback_ms())
+
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(min(P, max(count, 1)))]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        return res, fill_ms, tb_ms
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
-    fill_ms, tb_ms = [], []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sc, ln = step()
-        fill_ms.append(st.last_fill_ms())
-        tb_ms.append(st.last_traceback_ms())
+    res, fill_ovl, tb_ovl = run_steps(args.steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    assert len(res) == args.steps and len(set(res)) == 1, res
+    sc, ln = res[0]
     cells = float(n) * m
     ms_step = dt / args.steps * 1e3
+
+    # the same alignment alone on the GPU: latency of one pair, and the fill kernel's own duration
+    st = stripes[0]
+    ai0 = np.zeros(cap, np.int32); bj0 = np.zeros(cap, np.int32)
+    fill_ms, tb_ms = [], []
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    iso_reps = 3
+    for _ in range(iso_reps):
+        r = one_alignment(st, streams[0].cuda_stream, ai0, bj0)
+        assert r == (sc, ln)
+        fill_ms.append(st.last_fill_ms()); tb_ms.append(st.last_traceback_ms())
+    torch.cuda.synchronize()
+    lat_ms = (time.perf_counter() - t1) / iso_reps * 1e3
     fill = sum(fill_ms) / len(fill_ms)
+    fill_o = sum(fill_ovl) / len(fill_ovl)
     achieved = cells * OPS_PER_CELL_CODES / (fill * 1e-3) / 1e12
+    aggregate = cells * OPS_PER_CELL_CODES * args.steps / dt / 1e12
     code_bytes = st.code_bytes()
     traffic, traffic_src = pmc_traffic("fill_strips_v2<true>", 65536) if k == 16 else (None, None)
     out = {
-        "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of a 2^%d x 2^%d pair" % (k, k),
+        "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of 2^%d x 2^%d pairs" % (k, k),
         "value": cells / (dt / args.steps) / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "synthetic iid 20-letter protein pair 2^%d x 2^%d (mt19937_64 seeds 0xA/0xB0000000+%d), "
-                               "fill with packed winner codes in HBM + traceback walk + prefix fix-up" % (k, k, k),
-                   "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1},
-        "roofline": {"bound": "valu", "kernel": "fill_strips (with winner codes)", "achieved": achieved,
+                               "fill with packed winner codes in HBM + traceback walk + prefix fix-up; one step = one "
+                               "complete alignment, up to %d independent alignments in flight (a stream and a code "
+                               "buffer each)" % (k, k, k, P),
+                   "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1, "in_flight": P},
+        "roofline": {"bound": "valu", "kernel": "fill_strips_v2<true> (fill with winner codes)", "achieved": achieved,
                      "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
-                     "ops_per_cell": OPS_PER_CELL_CODES, "kernel_ms": fill, "fill_gcups": cells / (fill * 1e-3) / 1e9,
-                     "structural_ceiling": min(1.0, cells / ((n + m) * 65536.0)),
+                     "ops_per_cell": OPS_PER_CELL_CODES, "kernel_ms": fill,
+                     "kernel_ms_note": "HIP events around the launch, alignment alone on the GPU (%d launches after the "
+                                       "timed region); launches of the timed region overlap each other" % iso_reps,
+                     "launch_ms_overlapped": fill_o, "fill_gcups": cells / (fill * 1e-3) / 1e9,
+                     "aggregate_achieved": aggregate, "aggregate_frac": aggregate / VALU_PEAK_TOPS,
+                     "structural_ceiling_one_pair": min(1.0, cells / ((n + m) * 65536.0)),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (separate --pmc passes)",
                      "traffic_source": traffic_src,
                      "code_stream": {"bytes": code_bytes, "GBps": code_bytes / (fill * 1e-3) / 1e9,
                                      "frac_of_hbm_peak": code_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        "one_pair_alone": {"ms": lat_ms, "gcups": cells / (lat_ms * 1e-3) / 1e9, "fill_ms": fill,
+                           "traceback_ms": sum(tb_ms) / len(tb_ms)},
         "traceback_ms": sum(tb_ms) / len(tb_ms),
     }
+    for s_ in stripes[1:]:
+        s_.close()
+    stream = streams[0].cuda_stream
     st.close()
     extra = {}
     if not args.no_extra:

@@ -21,6 +21,9 @@
 
 namespace psa {
 
+#ifndef PSA_WAVES_PER_EU
+#define PSA_WAVES_PER_EU 1
+#endif
 #ifndef PSA_GDIST
 #define PSA_GDIST 2
 #endif
@@ -447,7 +450,7 @@ template <bool CODES>
 // One workgroup per CU, one wavefront per SIMD: every strip is a link of one dependency chain, so
 // two workgroups sharing a CU (each at half speed) would hold up every strip behind them.  The
 // occupancy attribute makes the register budget 512 per wave and keeps a second workgroup out.
-__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void fill_strips_v2(FillArgs2 q) {
+__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WAVES_PER_EU, PSA_WAVES_PER_EU))) void fill_strips_v2(FillArgs2 q) {
     __shared__ FillLds lds;
     __shared__ unsigned wg_ticket;
     const FillArgs& p = q.base;

@@ -337,7 +337,7 @@ int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io,
     HIP_TRY(hipMemcpyAsync(state, s->tb_state, sizeof state, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: len %lld iterations %lld runs/tiles %lld misses %lld\n", (long long)state[4], (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)state[7]);
-    if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld\n", (long long)state[8], (long long)state[9]);
+    if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld; sections %lld %lld %lld %lld\n", (long long)state[8], (long long)state[9], (long long)(state[10] >> 32), (long long)(state[10] & 0xffffffff), (long long)(state[11] >> 32), (long long)(state[11] & 0xffffffff));
     if (state[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow");
     const int64_t got = state[4];
     if (*len_io + got > cap) return fail(PSA_E_ARG, "psa_stripe_traceback: output capacity %lld too small", (long long)cap);

@@ -374,18 +374,27 @@ __global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
 //     lives in lanes 0..15 of two VGPRs: a lookup is one compare + ballot, no LDS round trip;
 //   * tiles are fetched ahead of the walk along its current diagonal (LDS-DMA, asynchronous);
 //     entering a tile waits only for that tile's fetch: "all but the N most recent vector-memory
-//     operations are complete" with N = 3 x (tiles requested after it);
+//     operations are complete", N = the operations issued after it.  To make N known exactly the
+//     output columns go out through buffer stores that are issued unconditionally, two per step
+//     (lanes that have nothing to write aim past the end of the buffer and are dropped);
 //   * in table 1 one ballot pass handles a whole diagonal run AND the non-diagonal step that
 //     ends it (its two bits sit in the word the lane already holds).
 constexpr int kTb3Ahead = 6;
 
 __device__ __forceinline__ void tb_wait_vm(int n_after) {
-    // wait until the fetch that has n_after tile fetches (3 instructions each) behind it is complete
-    if (n_after >= 16) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-    else if (n_after >= 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else if (n_after >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (n_after >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if (n_after >= 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    // wait until at most n_after vector-memory operations are outstanding (rounded down to a value that
+    // exists as an immediate here): everything issued before the n_after most recent ones is complete
+    if (n_after >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (n_after >= 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (n_after >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n_after >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n_after >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n_after >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n_after >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n_after >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n_after >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (n_after >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (n_after >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -397,15 +406,23 @@ __global__ __launch_bounds__(64) void traceback_v3(TraceArgs p) {
     int k = __builtin_amdgcn_readfirstlane((int)p.state[2]);
     const int c0 = (int)p.c0;
     const int Q = p.Q;
-    const int cap = (int)(p.cap < 0x7fffff00 ? p.cap : 0x7fffff00);
+    const int cap = (int)(p.cap < 0x1fffff00 ? p.cap : 0x1fffff00);   // 4 * cap fits the buffer descriptor
     int len = 0, done = 0, err = 0;
-    int my_tile = -1, my_seq = 0;          // lanes 0..15: directory of the LDS slots
-    int victim = 0, seq_issued = 0, seq_done = 0;
+    int my_tile = -1, my_ops = 0;          // lanes 0..15: directory of the LDS slots (tile id, op count after its fetch)
+    int victim = 0, ops = 0, ops_done = 0; // ops: vector-memory instructions issued so far
+    const __amdgpu_buffer_rsrc_t rs_ai = __builtin_amdgcn_make_buffer_rsrc(p.out_ai, 0, cap * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bj = __builtin_amdgcn_make_buffer_rsrc(p.out_bj, 0, cap * 4, 0x00020000);
     int cur_T = -1, cur_slot = 0;
     int cpi = 0, ahead = 0;                // prefetch cursor: a row on the walk's diagonal, tiles ahead
     int n_iter = 0, n_miss = 0, n_tiles = 0;
     const uint4* codes4 = (const uint4*)p.codes;
     const long long tc0 = (long long)__builtin_readcyclecounter(), tw0 = (long long)wall_clock64();
+#ifdef PSA_TB_TIMING
+    long long tsec[4] = {0, 0, 0, 0}, tmark = tc0;
+#define TB_MARK(x) { const long long now_ = (long long)__builtin_readcyclecounter(); tsec[x] += now_ - tmark; tmark = now_; }
+#else
+#define TB_MARK(x)
+#endif
 
     auto lookup = [&](int T) -> int {
         const unsigned long long m = __ballot(my_tile == T);
@@ -417,8 +434,8 @@ __global__ __launch_bounds__(64) void traceback_v3(TraceArgs p) {
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(codes4 + ((long long)T * 3 + kind) * 64 + lane),
                 (__attribute__((address_space(3))) void*)&tile[victim][kind][0], 16, 0, 0);
-        ++seq_issued;
-        if (lane == victim) { my_tile = T; my_seq = seq_issued; }
+        ops += 3;
+        if (lane == victim) { my_tile = T; my_ops = ops; }
         victim = (victim + 1) & (kTbSlots - 1);
     };
 
@@ -432,9 +449,11 @@ __global__ __launch_bounds__(64) void traceback_v3(TraceArgs p) {
             boundary_triple(pi, pj, t1, t2, t3);
             const int w = winner_plain(t1, t2, t3, k);
             if (len >= cap) { err = 1; break; }
-            if (lane == 0) {
-                p.out_ai[len] = (w == 2) ? -1 : (i - 1);
-                p.out_bj[len] = (w == 3) ? -1 : (j - 1);
+            {
+                const int off = lane == 0 ? 4 * len : -1;
+                __builtin_amdgcn_raw_buffer_store_b32((w == 2) ? -1 : (i - 1), rs_ai, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32((w == 3) ? -1 : (j - 1), rs_bj, off, 0, 0);
+                ops += 2;
             }
             ++len; i = pi; j = pj; k = w;
             continue;
@@ -474,61 +493,87 @@ __global__ __launch_bounds__(64) void traceback_v3(TraceArgs p) {
                 ++ahead;
             }
             // the tile being entered must have landed
-            const int sq = __builtin_amdgcn_readlane(my_seq, slot);
-            if (sq > seq_done) { tb_wait_vm(seq_issued - sq); seq_done = sq; }
+            const int sq = __builtin_amdgcn_readlane(my_ops, slot);
+            if (sq > ops_done) { tb_wait_vm(ops - sq); ops_done = sq; }
             __builtin_amdgcn_s_barrier();   // single wave: orders the LDS reads below behind the wait
             cur_T = T; cur_slot = slot;
         }
-        const int slot = cur_slot;
-        if (k == 1) {
-            // lane l' looks at cell (pi - d, pj - d), d = lp - l': a run of "table 1 wins" bits from
-            // lane lp downwards is a diagonal run; the first cell without the bit (if it is still
-            // inside this tile and stripe) gives the step that follows the run
-            const int d = lp - lane;
-            const int tt = t - 2 * d;
-            const bool valid = d >= 0 && tt >= (q << 6) && (pj - d) >= c0 + 1;
-            unsigned pair = 0;
-            if (valid) {
-                const uint32_t* wp = (const uint32_t*)&tile[slot][0][lane];
-                pair = (wp[(tt & 63) >> 4] >> (2 * (15 - (tt & 15)))) & 3u;
+        // ---- inside the tile: the walk goes on in tile-local coordinates (lane ll, step tl of the
+        // predecessor cell) until it leaves the tile, the stripe or the matrix ----
+        const uint32_t* tile_w = (const uint32_t*)&tile[cur_slot][0][0];   // [kind][lane][4] dwords
+        int ll = lp, tl = t & 63;
+        int gi = pi, gj = pj;   // the predecessor cell; the walk stands on (gi + (k != 2), gj + (k != 3)) in table k
+        --n_iter;
+        TB_MARK(0)
+        do {
+            ++n_iter;
+            if (k == 1) {
+                // lane l' looks at cell (gi - d, gj - d), d = ll - l': a run of "table 1 wins" bits from
+                // lane ll downwards is a diagonal run; the first cell without the bit (if it is still
+                // inside this tile and stripe) gives the step that follows the run
+                const int dlim = min(tl >> 1, gj - c0 - 1);
+                const int d = ll - lane;
+                const int tt = tl - 2 * d;
+                const bool valid = (unsigned)d <= (unsigned)dlim;
+                unsigned pair = 0;
+                if (valid) pair = (tile_w[lane * 4 + (tt >> 4)] >> (2 * (15 - (tt & 15)))) & 3u;
+                const unsigned long long mv = __ballot(valid);
+                const unsigned long long m1 = __ballot((pair & 2u) != 0);
+                const unsigned long long m23 = __ballot((pair & 1u) != 0);
+                TB_MARK(1)
+                const unsigned long long upto = (2ull << ll) - 1;           // lanes 0..ll (ll = 63: wraps to all ones)
+                const unsigned long long inv = ~m1 & upto;
+                const int lr = inv ? 63 - (int)__builtin_clzll(inv) : -1;   // lane of the first cell that is not a diagonal move
+                const int r = ll - lr;                                       // run length
+                const bool has_g = lr >= 0 && ((mv >> lr) & 1ull);
+                const int w = ((m23 >> (lr & 63)) & 1ull) ? 2 : 3;
+                const int cnt = r + (has_g ? 1 : 0);
+                if (len + cnt > cap) { err = 1; break; }
+                {
+                    const bool g = (d == r);
+                    const int off = (unsigned)d < (unsigned)cnt ? 4 * (len + d) : -1;   // -1: past the end, dropped
+                    __builtin_amdgcn_raw_buffer_store_b32((g && w == 2) ? -1 : (gi - d), rs_ai, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((g && w == 3) ? -1 : (gj - d), rs_bj, off, 0, 0);
+                    ops += 2;
+                }
+                len += cnt;
+                if (has_g) {
+                    k = w;
+                    gi -= r + (w != 2); gj -= r + (w != 3);
+                    ll = lr - (w != 2); tl -= 2 * r + 1;
+                } else {
+                    gi -= r; gj -= r; ll = lr; tl -= 2 * r;
+                }
+                TB_MARK(2)
+            } else {
+                // tables 2 and 3 (inside a gap): one step
+                const uint32_t word = __builtin_amdgcn_readfirstlane(tile_w[(k - 1) * 256 + ll * 4 + (tl >> 4)]);
+                const unsigned pair = (word >> (2 * (15 - (tl & 15)))) & 3u;
+                const int w = (pair & 2u) ? 1 : ((pair & 1u) ? 2 : 3);
+                if (len >= cap) { err = 1; break; }
+                {
+                    const int off = lane == 0 ? 4 * len : -1;
+                    __builtin_amdgcn_raw_buffer_store_b32((w == 2) ? -1 : (gi - (k == 2)), rs_ai, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((w == 3) ? -1 : (gj - (k == 3)), rs_bj, off, 0, 0);
+                    ops += 2;
+                }
+                ++len;
+                k = w;
+                ll -= (w != 2); tl -= (w != 2) + (w != 3);
+                gi -= (w != 2); gj -= (w != 3);
+                TB_MARK(3)
             }
-            const unsigned long long mv = __ballot(valid);
-            const unsigned long long m1 = __ballot(valid && (pair & 2u));
-            const unsigned long long m23 = __ballot(valid && (pair & 1u));
-            const unsigned long long upto = (lp == 63) ? ~0ull : ((1ull << (lp + 1)) - 1);
-            const unsigned long long inv = ~m1 & upto;
-            const int lr = inv ? 63 - (int)__builtin_clzll(inv) : -1;   // lane of the first cell that is not a diagonal move
-            const int r = lp - lr;                                       // run length (lp + 1 when the run leaves the tile's rows)
-            const bool has_g = lr >= 0 && ((mv >> lr) & 1ull);
-            const int w = ((m23 >> (lr & 63)) & 1ull) ? 2 : 3;
-            const int cnt = r + (has_g ? 1 : 0);
-            if (len + cnt > cap) { err = 1; break; }
-            if (d >= 0 && d < cnt) {
-                const bool g = (d == r);
-                p.out_ai[len + d] = (g && w == 2) ? -1 : (pi - d);
-                p.out_bj[len + d] = (g && w == 3) ? -1 : (pj - d);
-            }
-            len += cnt;
-            if (has_g) { i = pi - r; j = pj - r; k = w; }
-            else { i -= r; j -= r; }
-            continue;
-        }
-        // tables 2 and 3 (inside a gap): one step
-        const uint32_t* wp = (const uint32_t*)&tile[slot][k - 1][lp];
-        const uint32_t word = __builtin_amdgcn_readfirstlane(wp[(t & 63) >> 4]);
-        const unsigned pair = (word >> (2 * (15 - (t & 15)))) & 3u;
-        const int w = (pair & 2u) ? 1 : ((pair & 1u) ? 2 : 3);
-        if (len >= cap) { err = 1; break; }
-        if (lane == 0) {
-            p.out_ai[len] = (w == 2) ? -1 : (i - 1);
-            p.out_bj[len] = (w == 3) ? -1 : (j - 1);
-        }
-        ++len; i = pi; j = pj; k = w;
+        } while (ll >= 0 && tl >= 0 && gj > c0 && gi >= 1);
+        if (err) break;
+        i = gi + (k != 2); j = gj + (k != 3);
     }
     if (lane == 0) {
         p.state[0] = i; p.state[1] = j; p.state[2] = k; p.state[3] = done; p.state[4] = len; p.state[5] = err;
         p.state[6] = ((long long)n_iter << 32) | (unsigned)n_tiles; p.state[7] = n_miss;
         p.state[8] = (long long)__builtin_readcyclecounter() - tc0; p.state[9] = (long long)wall_clock64() - tw0;
+#ifdef PSA_TB_TIMING
+        p.state[10] = (tsec[0] << 32) | (tsec[1] & 0xffffffffLL); p.state[11] = (tsec[2] << 32) | (tsec[3] & 0xffffffffLL);
+#endif
     }
 }
 
