@@ -10,8 +10,9 @@
 // (simple.cpp:162/166/170 ...) is a property of the SOURCE cell: for each aggregate two bits
 //     b1  = (x1 == aggregate)            table 1 wins
 //     b23 = (x2(+2) >= x3(+2))           else table 2 before table 3
-// are recorded with the source cell; the traceback of a cell in table k reads the bits of its
-// predecessor cell for aggregate k.
+// are recorded with the source cell (the three b23 as one clamped difference, see "packed winner
+// codes" below); the traceback of a cell in table k reads the bits of its predecessor cell for
+// aggregate k.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,11 +48,37 @@ __device__ __host__ __forceinline__ int winner_plain(int t1, int t2, int t3, int
     return t2 >= t3 ? 2 : 3;
 }
 
-// Packed winner bits: per strip (64 rows), per block of 64 wavefront steps, per aggregate,
-// per lane, four dwords; dword d holds steps 16d..16d+15, step u in bits 31-2u (b1), 30-2u (b23).
+// Packed winner codes: per strip (64 rows), per block of 64 wavefront steps ("tile"), three parts,
+// per lane, four dwords (48 bytes per lane and tile = 0.75 byte per cell):
+//   part 0, 1: eight words of eight 4-bit steps; word u>>3 holds step u (0..63) in bits 4*(7-(u&7))..+3
+//              as nibble 2*(q'+3) + b1_D, q' = clamp(x2 - x3, -3, 2), b1_D = (x1 == D), AFTER
+//              kCodeBias has been added to the stored word (the writer accumulates signed q')
+//   part 2:    dwords 0,1: b1_H = (x1 == H') of steps 0..31 / 32..63, step u in bit 31-(u&31);
+//              dwords 2,3: b1_V = (x1 == V') likewise
+// The three "table 2 before table 3" bits follow from q' = x2 - x3 clamped:
+//   D: x2 >= x3  <=> q' >= 0;   H': x2 + 2 >= x3  <=> q' >= -2;   V': x2 >= x3 + 2  <=> q' >= 2.
+constexpr uint32_t kCodeBias = 0x66666666u;
+
 __device__ __host__ __forceinline__ int64_t code_word_index(int64_t strip, int64_t qblocks, int64_t q,
-                                                            int kind0, int lane, int d) {
-    return ((((strip * qblocks + q) * 3 + kind0) * 64 + lane) * 4) + d;
+                                                            int part, int lane, int d) {
+    return ((((strip * qblocks + q) * 3 + part) * 64 + lane) * 4) + d;
+}
+// word offsets inside one tile ([part][lane][4] dwords) of step u's nibble word and b1_H / b1_V word
+__device__ __host__ __forceinline__ int code_q_offset(int lane, int u) { return ((u >> 5) * 64 + lane) * 4 + ((u >> 3) & 3); }
+__device__ __host__ __forceinline__ int code_hv_offset(int lane, int u, int kind) {
+    return (2 * 64 + lane) * 4 + (kind == 3 ? 2 : 0) + (u >> 5);
+}
+// winner (1, 2 or 3) for aggregate `kind` (1 = D, 2 = H', 3 = V') from step u's words
+__device__ __host__ __forceinline__ int code_winner(uint32_t qword, uint32_t hvword, int u, int kind) {
+    const unsigned nib = ((qword + kCodeBias) >> (4 * (7 - (u & 7)))) & 15u;
+    const unsigned q3 = nib >> 1;   // q' + 3, 0..5
+    bool b1, b23;
+    if (kind == 1) { b1 = nib & 1u; b23 = q3 >= 3; }
+    else {
+        b1 = (hvword >> (31 - (u & 31))) & 1u;
+        b23 = (kind == 2) ? (q3 >= 1) : (q3 >= 5);
+    }
+    return b1 ? 1 : (b23 ? 2 : 3);
 }
 
 }  // namespace psa

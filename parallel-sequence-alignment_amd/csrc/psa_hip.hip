@@ -328,8 +328,7 @@ int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io,
         const bool fits32 = s->n < 0x7fff0000LL && s->c0 + s->W < 0x7fff0000LL &&
                             ((s->n + 63) / 64) * (int64_t)s->Q < 0x7fff0000LL;
         if ((force && !strcmp(force, "v1")) || !fits32) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
-        else if (force && !strcmp(force, "v2")) hipLaunchKernelGGL(psa::traceback_v2, dim3(1), dim3(64), 0, st, ta);
-        else hipLaunchKernelGGL(psa::traceback_v3, dim3(1), dim3(64), 0, st, ta);
+        else hipLaunchKernelGGL(psa::traceback_wave, dim3(1), dim3(64), 0, st, ta);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[3], st));

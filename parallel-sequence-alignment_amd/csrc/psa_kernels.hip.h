@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void fill_strips_v1(FillArgs p) {
     int Dtop_prev = __builtin_amdgcn_readfirstlane(D_up);  // lane 0's up-left input
     const int a_res = row_ok ? (int)p.a[i - 1] : 0x100;
     int bsh = 0x200;                   // B residues shift down the lanes with the wavefront
-    unsigned accD = 0, accH = 0, accV = 0;
+    unsigned accQ = 0, accH = 0, accV = 0;
     int topD = 0, topV = 0, bch = 0;
     const u64* ring_in = p.ring + (size_t)((sg + 1) & 1) * p.Wpad;  // parity of strip sg-1
     u64* ring_out = p.ring + (size_t)(sg & 1) * p.Wpad;
@@ -147,9 +147,16 @@ __global__ __launch_bounds__(64) void fill_strips_v1(FillArgs p) {
                 const int Hn = max(D, x2 + 2);
                 const int Vn = max(D, x3 + 2);
                 if (CODES) {
-                    accD = (accD << 2) | ((unsigned)(x1 == D) << 1) | (unsigned)(x2 >= x3);
-                    accH = (accH << 2) | ((unsigned)(x1 == Hn) << 1) | (unsigned)(x2 + 2 >= x3);
-                    accV = (accV << 2) | ((unsigned)(x1 == Vn) << 1) | (unsigned)(x2 >= x3 + 2);
+                    // layout: psa_device.hip.h, "packed winner codes" (accQ sums signed nibbles, like fill_strips_v2)
+                    const int qc = min(max(x2 - x3, -3), 2);
+                    accQ = (accQ << 4) + (unsigned)(2 * qc + (int)(x1 == D));
+                    accH = (accH << 1) | (unsigned)(x1 == Hn);
+                    accV = (accV << 1) | (unsigned)(x1 == Vn);
+                    if ((k & 7) == 7) p.codes[code_word_index(sg, p.Q, q, k >> 5, lane, (k >> 3) & 3)] = accQ;
+                    if ((k & 31) == 31) {
+                        p.codes[code_word_index(sg, p.Q, q, 2, lane, k >> 5)] = accH;
+                        p.codes[code_word_index(sg, p.Q, q, 2, lane, 2 + (k >> 5))] = accV;
+                    }
                 }
                 if (act) {
                     if (k & 1) Dreg1 = D; else Dreg0 = D;
@@ -177,11 +184,6 @@ __global__ __launch_bounds__(64) void fill_strips_v1(FillArgs p) {
                         __syncthreads();
                     }
                 }
-            }
-            if (CODES) {
-                p.codes[code_word_index(sg, p.Q, q, 0, lane, d)] = accD;
-                p.codes[code_word_index(sg, p.Q, q, 1, lane, d)] = accH;
-                p.codes[code_word_index(sg, p.Q, q, 2, lane, d)] = accV;
             }
         }
     }
@@ -217,9 +219,9 @@ __global__ __launch_bounds__(64) void traceback_v1(TraceArgs p) {
             const int64_t strip = (pi - 1) >> 6;
             const int lane = (int)((pi - 1) & 63);
             const int64_t t = (pj - c0 - 1) + lane;
-            const uint32_t word = p.codes[code_word_index(strip, p.Q, t >> 6, k - 1, lane, (int)((t & 63) >> 4))];
-            const unsigned pair = (word >> (2 * (15 - (int)(t & 15)))) & 3u;
-            w = (pair & 2u) ? 1 : ((pair & 1u) ? 2 : 3);
+            const uint32_t* tw = p.codes + code_word_index(strip, p.Q, t >> 6, 0, 0, 0);
+            const int u = (int)(t & 63);
+            w = code_winner(tw[code_q_offset(lane, u)], k == 1 ? 0u : tw[code_hv_offset(lane, u, k)], u, k);
         }
         if (len >= p.cap) { err = 1; break; }
         p.out_ai[len] = (w == 2) ? -1 : (int32_t)(i - 1);
@@ -231,143 +233,14 @@ __global__ __launch_bounds__(64) void traceback_v1(TraceArgs p) {
 }
 
 
-// ---- traceback, wave-cooperative (production) ----
-// The packed winner bits are stored in tiles of 64 rows x 64 wavefront steps (3 KB: three
-// aggregates x 64 lanes x 16 bytes), the unit the fill kernel writes.  One wavefront walks:
-//   * tiles are cached in LDS; on a miss the tile and the next tiles a pure diagonal would
-//     visit are fetched together (one memory latency per batch instead of per tile);
+// The packed winner codes are stored in tiles of 64 rows x 64 wavefront steps (3 KB: three parts
+// x 64 lanes x 16 bytes), the unit the fill kernel writes; the wave-cooperative walk caches tiles in LDS.
+constexpr int kTbSlots = 16;
+
+// ---- traceback, wave-cooperative (production): one wavefront walks ----
 //   * while the walk is in table 1 and the predecessor's "table 1 wins" bit is set it moves on a
 //     diagonal: all 64 lanes test their own row's bit at once, a ballot gives the run length
 //     inside the tile and the lanes emit the run's columns in parallel;
-//   * everything else is one scalar step (same semantics as traceback_v1).
-constexpr int kTbSlots = 16;
-constexpr int kTbBatch = 8;
-
-__global__ __launch_bounds__(64) void traceback_v2(TraceArgs p) {
-    __shared__ uint4 tile[kTbSlots][3][64];
-    __shared__ long long slot_tile[kTbSlots];
-    const int lane = threadIdx.x;
-    // the walk state is wave-uniform: keep it in SGPRs so that its arithmetic and branches are scalar
-    auto uni64 = [](int64_t x) -> int64_t {
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x);
-        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)x >> 32));
-        return (int64_t)(((unsigned long long)hi << 32) | lo);
-    };
-    int64_t i = uni64(p.state[0]), j = uni64(p.state[1]);
-    int k = __builtin_amdgcn_readfirstlane((int)p.state[2]);
-    int64_t len = 0, done = 0, err = 0;
-    const int64_t c0 = p.c0;
-    const int64_t Q = p.Q;
-    if (lane < kTbSlots) slot_tile[lane] = -1;
-    __syncthreads();
-    int victim = 0;
-    long long n_iter = 0, n_miss = 0, n_run = 0;
-    long long cur_T = -1;
-    int cur_slot = -1;
-    const uint4* codes4 = (const uint4*)p.codes;
-
-    auto lookup = [&](long long T) -> int {
-        const long long id = slot_tile[lane & (kTbSlots - 1)];
-        const unsigned long long m = __ballot(lane < kTbSlots && id == T);
-        return m ? (int)__builtin_ctzll(m) : -1;
-    };
-
-    for (;;) {
-        if (i == 0 || j == 0) { done = 1; break; }
-        ++n_iter;
-        const int64_t pi = i - (k != 2), pj = j - (k != 3);
-        if (c0 > 0 && pj <= c0) break;  // predecessor belongs to the stripe on the left
-        int w;
-        if (pi == 0 || pj == 0) {
-            int t1, t2, t3;
-            boundary_triple(pi, pj, t1, t2, t3);
-            w = winner_plain(t1, t2, t3, k);
-        } else {
-            const int64_t strip = (pi - 1) >> 6;
-            const int lp = (int)((pi - 1) & 63);
-            const int64_t t = (pj - c0 - 1) + lp;
-            const int64_t q = t >> 6;
-            const long long T = strip * Q + q;
-            int slot = cur_slot;
-            if (T != cur_T) slot = lookup(T);
-            if (slot < 0) {
-                ++n_miss;
-                // fetch T and the tiles a diagonal continuation would visit next: LDS-DMA, one
-                // 1-KB instruction per aggregate and tile, all in flight together, one wait
-                int64_t cpi = pi, cpj = pj;
-                for (int b = 0; b < kTbBatch; ++b) {
-                    if (cpi < 1 || cpj < c0 + 1) break;
-                    const int64_t bs = (cpi - 1) >> 6;
-                    const int bl = (int)((cpi - 1) & 63);
-                    const int64_t bt = (cpj - c0 - 1) + bl;
-                    const int64_t bq = bt >> 6;
-                    const long long Tb = bs * Q + bq;
-                    if (lookup(Tb) < 0) {
-#pragma unroll
-                        for (int kind = 0; kind < 3; ++kind)
-                            __builtin_amdgcn_global_load_lds(
-                                (const __attribute__((address_space(1))) void*)(codes4 + (Tb * 3 + kind) * 64 + lane),
-                                (__attribute__((address_space(3))) void*)&tile[victim][kind][0], 16, 0, 0);
-                        if (lane == 0) slot_tile[victim] = Tb;
-                        victim = (victim + 1) & (kTbSlots - 1);
-                    }
-                    const int64_t s1 = ((bt - (bq << 6)) >> 1) + 1, s2 = bl + 1;
-                    const int64_t sdiag = s1 < s2 ? s1 : s2;
-                    cpi -= sdiag; cpj -= sdiag;
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                slot = lookup(T);
-            }
-            cur_T = T;
-            cur_slot = slot;
-            if (k == 1) {
-                // diagonal run inside this tile: lane l' looks at cell (pi - d, pj - d), d = lp - l'
-                const int d = lp - lane;
-                const int64_t tt = t - 2 * d;
-                const bool valid = d >= 0 && tt >= (q << 6) && (pj - d) >= c0 + 1;
-                unsigned bit = 0;
-                if (valid) {
-                    const uint32_t* wp = (const uint32_t*)&tile[slot][0][lane];
-                    const uint32_t word = wp[(tt & 63) >> 4];
-                    bit = (word >> (2 * (15 - (int)(tt & 15)) + 1)) & 1u;
-                }
-                const unsigned long long mask = __ballot(valid && bit);
-                const unsigned long long upto = (lp == 63) ? ~0ull : ((1ull << (lp + 1)) - 1);
-                const unsigned long long inv = ~mask & upto;
-                const int r = inv ? lp - (63 - (int)__builtin_clzll(inv)) : lp + 1;
-                if (r > 0) {
-                    if (len + r > p.cap) { err = 1; break; }
-                    if (d >= 0 && d < r) {
-                        p.out_ai[len + d] = (int32_t)(pi - d);
-                        p.out_bj[len + d] = (int32_t)(pj - d);
-                    }
-                    len += r; i -= r; j -= r;
-                    ++n_run;
-                    continue;
-                }
-            }
-            const uint32_t* wp = (const uint32_t*)&tile[slot][k - 1][lp];
-            const uint32_t word = __builtin_amdgcn_readfirstlane(wp[(t & 63) >> 4]);
-            const unsigned pair = (word >> (2 * (15 - (int)(t & 15)))) & 3u;
-            w = (pair & 2u) ? 1 : ((pair & 1u) ? 2 : 3);
-        }
-        if (len >= p.cap) { err = 1; break; }
-        if (lane == 0) {
-            p.out_ai[len] = (w == 2) ? -1 : (int32_t)(i - 1);
-            p.out_bj[len] = (w == 3) ? -1 : (int32_t)(j - 1);
-        }
-        ++len;
-        i = pi; j = pj; k = w;
-    }
-    if (lane == 0) {
-        p.state[0] = i; p.state[1] = j; p.state[2] = k; p.state[3] = done; p.state[4] = len; p.state[5] = err;
-        p.state[6] = (n_iter << 32) | n_run; p.state[7] = n_miss;
-    }
-}
-
-// ---- traceback, third version: 32-bit scalar state, tile directory in registers, prefetch ----
-// Same walk as traceback_v2 with the per-iteration cost cut down:
 //   * the walk state (i, j, table, output length, tile ids) is 32-bit and wave-uniform (SGPRs);
 //     the host checks that the stripe's coordinates and tile count fit (else traceback_v1 runs);
 //   * the tile directory (which tile sits in which LDS slot, and the issue number of its fetch)
@@ -398,7 +271,7 @@ __device__ __forceinline__ void tb_wait_vm(int n_after) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(64) void traceback_v3(TraceArgs p) {
+__global__ __launch_bounds__(64) void traceback_wave(TraceArgs p) {
     __shared__ uint4 tile[kTbSlots][3][64];
     const int lane = threadIdx.x;
     int i = __builtin_amdgcn_readfirstlane((int)p.state[0]);
@@ -516,7 +389,11 @@ __global__ __launch_bounds__(64) void traceback_v3(TraceArgs p) {
                 const int tt = tl - 2 * d;
                 const bool valid = (unsigned)d <= (unsigned)dlim;
                 unsigned pair = 0;
-                if (valid) pair = (tile_w[lane * 4 + (tt >> 4)] >> (2 * (15 - (tt & 15)))) & 3u;
+                if (valid) {
+                    // aggregate D of step tt: nibble 2*(q'+3) + b1; pair = (b1, q' >= 0)
+                    const unsigned nib = ((tile_w[code_q_offset(lane, tt)] + kCodeBias) >> (4 * (7 - (tt & 7)))) & 15u;
+                    pair = ((nib & 1u) << 1) | (nib >= 6u ? 1u : 0u);
+                }
                 const unsigned long long mv = __ballot(valid);
                 const unsigned long long m1 = __ballot((pair & 2u) != 0);
                 const unsigned long long m23 = __ballot((pair & 1u) != 0);
@@ -547,9 +424,9 @@ __global__ __launch_bounds__(64) void traceback_v3(TraceArgs p) {
                 TB_MARK(2)
             } else {
                 // tables 2 and 3 (inside a gap): one step
-                const uint32_t word = __builtin_amdgcn_readfirstlane(tile_w[(k - 1) * 256 + ll * 4 + (tl >> 4)]);
-                const unsigned pair = (word >> (2 * (15 - (tl & 15)))) & 3u;
-                const int w = (pair & 2u) ? 1 : ((pair & 1u) ? 2 : 3);
+                const uint32_t qw = __builtin_amdgcn_readfirstlane(tile_w[code_q_offset(ll, tl)]);
+                const uint32_t hw = __builtin_amdgcn_readfirstlane(tile_w[code_hv_offset(ll, tl, k)]);
+                const int w = code_winner(qw, hw, tl, k);
                 if (len >= cap) { err = 1; break; }
                 {
                     const int off = lane == 0 ? 4 * len : -1;
