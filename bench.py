@@ -6,13 +6,16 @@
 One "step" = one complete alignment of the workload pair: DP fill with packed winner codes
 written to HBM, final pick, traceback walk, prefix fix-up (what run() does in simple.cpp:261-294).
 Inputs are resident in HBM before the timed region.  N = 1: the synthetic 2^16 x 2^16 protein
-pair of BASELINE config 4 on one GPU.  One pair alone cannot fill the GPU (its anti-diagonal
+pair of BASELINE config 4 on one GPU.  N > 1 (launched by torch.distributed.run, one rank per
+GPU): every rank does the same with its own pairs, no data-path communication (weak scaling; the
+"batched many-pair" sharding of the north star); --mode stripes instead cuts ONE pair into N
+column stripes, boundary columns streamed g -> g+1 with RCCL send/recv (bench_multi.py; its
+dependency chain is n + m steps long on any number of GPUs, so it buys capacity, not time, at
+2^16).  One pair alone cannot fill the GPU (its anti-diagonal
 dependency chain is n + m steps long whatever the hardware), so the job keeps --in-flight
 (default 3) independent alignments going at a time, each on its own stream with its own code
 buffer; "value" is the job's throughput, "one_pair_alone" the latency of a single alignment, and
-the roofline object is the fill kernel measured alone.  N > 1 (launched by torch.distributed.run, one rank per
-GPU): the same pair cut into N column stripes, stripe g on GPU g, boundary columns streamed
-g -> g+1 with RCCL send/recv in row chunks (strong scaling).  Rank 0 prints ONE JSON line.
+the roofline object is the fill kernel measured alone.  Rank 0 prints ONE JSON line.
 
 Extra keys beside the contract: roofline (int32 VALU), cpu_baseline (the oracle's
 multi-threaded port timed on host cores, rank 0, N = 1 only), and secondary measurements
@@ -42,6 +45,8 @@ def parse():
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1)")
     ap.add_argument("--in-flight", type=int, default=3, help="independent alignments in flight (N = 1)")
+    ap.add_argument("--mode", choices=["pairs", "stripes"], default="pairs",
+                    help="N > 1: independent pairs per GPU (default) or one pair in N column stripes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
@@ -88,8 +93,22 @@ def single_gpu(args):
     import numpy as np
     import torch
     import psa_amd
-    torch.cuda.set_device(0)
-    psa_amd.set_device(0)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("PSA_BENCH_BACKEND", "nccl")   # gloo: rehearsal of the N > 1 logic on one GPU
+    torch.cuda.set_device(local)
+    psa_amd.set_device(local)
+    dist = None
+    if world > 1:
+        # independent alignments per rank: no data-path communication, only the timing barrier
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     k = args.log2n
     n = m = 1 << k
     a = psa_amd.synth_protein(0xA0000000 + k, n)
@@ -137,15 +156,30 @@ def single_gpu(args):
         return res, fill_ms, tb_ms
 
     run_steps(args.warmup)
+    if dist:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     res, fill_ovl, tb_ovl = run_steps(args.steps)
     torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if dist:
+        dtt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
+        dt = float(dtt.item())
     assert len(res) == args.steps and len(set(res)) == 1, res
     sc, ln = res[0]
-    cells = float(n) * m
+    cells = float(n) * m * world          # per step: one alignment on every rank
     ms_step = dt / args.steps * 1e3
+    if rank != 0:
+        for s_ in stripes:
+            s_.close()
+        dist.barrier()                    # rank 0 is still measuring; leave together
+        dist.destroy_process_group()
+        return None
 
     # the same alignment alone on the GPU: latency of one pair, and the fill kernel's own duration
     st = stripes[0]
@@ -162,33 +196,35 @@ def single_gpu(args):
     lat_ms = (time.perf_counter() - t1) / iso_reps * 1e3
     fill = sum(fill_ms) / len(fill_ms)
     fill_o = sum(fill_ovl) / len(fill_ovl)
-    achieved = cells * OPS_PER_CELL_CODES / (fill * 1e-3) / 1e12
-    aggregate = cells * OPS_PER_CELL_CODES * args.steps / dt / 1e12
+    cells1 = float(n) * m
+    achieved = cells1 * OPS_PER_CELL_CODES / (fill * 1e-3) / 1e12
+    aggregate = cells * OPS_PER_CELL_CODES * args.steps / dt / 1e12 / world   # per GPU
     code_bytes = st.code_bytes()
     traffic, traffic_src = pmc_traffic("fill_strips_v2<true>", 65536) if k == 16 else (None, None)
     out = {
         "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of 2^%d x 2^%d pairs" % (k, k),
-        "value": cells / (dt / args.steps) / 1e9, "unit": "GCUPS", "n_gpus": 1, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+        "value": cells / (dt / args.steps) / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "synthetic iid 20-letter protein pair 2^%d x 2^%d (mt19937_64 seeds 0xA/0xB0000000+%d), "
                                "fill with packed winner codes in HBM + traceback walk + prefix fix-up; one step = one "
-                               "complete alignment, up to %d independent alignments in flight (a stream and a code "
-                               "buffer each)" % (k, k, k, P),
-                   "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1, "in_flight": P},
+                               "complete alignment per GPU, up to %d independent alignments in flight on each (a "
+                               "stream and a code buffer each); no inter-GPU communication" % (k, k, k, P),
+                   "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1, "in_flight": P,
+                   "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
         "roofline": {"bound": "valu", "kernel": "fill_strips_v2<true> (fill with winner codes)", "achieved": achieved,
                      "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
                      "ops_per_cell": OPS_PER_CELL_CODES, "kernel_ms": fill,
                      "kernel_ms_note": "HIP events around the launch, alignment alone on the GPU (%d launches after the "
                                        "timed region); launches of the timed region overlap each other" % iso_reps,
-                     "launch_ms_overlapped": fill_o, "fill_gcups": cells / (fill * 1e-3) / 1e9,
+                     "launch_ms_overlapped": fill_o, "fill_gcups": cells1 / (fill * 1e-3) / 1e9,
                      "aggregate_achieved": aggregate, "aggregate_frac": aggregate / VALU_PEAK_TOPS,
-                     "structural_ceiling_one_pair": min(1.0, cells / ((n + m) * 65536.0)),
+                     "structural_ceiling_one_pair": min(1.0, cells1 / ((n + m) * 65536.0)),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (separate --pmc passes)",
                      "traffic_source": traffic_src,
                      "code_stream": {"bytes": code_bytes, "GBps": code_bytes / (fill * 1e-3) / 1e9,
                                      "frac_of_hbm_peak": code_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-        "one_pair_alone": {"ms": lat_ms, "gcups": cells / (lat_ms * 1e-3) / 1e9, "fill_ms": fill,
+        "one_pair_alone": {"ms": lat_ms, "gcups": cells1 / (lat_ms * 1e-3) / 1e9, "fill_ms": fill,
                            "traceback_ms": sum(tb_ms) / len(tb_ms)},
         "traceback_ms": sum(tb_ms) / len(tb_ms),
     }
@@ -209,8 +245,8 @@ def single_gpu(args):
         t = so.final(stream)
         so.close()
         ms = sum(ts) / len(ts)
-        extra["score_only_2p%d" % k] = {"gcups": cells / (ms * 1e-3) / 1e9, "kernel_ms": ms, "score": int(max(t)),
-                                        "valu_frac": cells * OPS_PER_CELL_SCORE / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
+        extra["score_only_2p%d" % k] = {"gcups": cells1 / (ms * 1e-3) / 1e9, "kernel_ms": ms, "score": int(max(t)),
+                                        "valu_frac": cells1 * OPS_PER_CELL_SCORE / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
         # titin pair (BASELINE config 3), full alignment
         seqdir = os.path.join(ROOT, "tests", "golden", "sequences")
         ta = psa_amd.read_fasta(os.path.join(seqdir, "titin_homo(50).fasta"))
@@ -225,19 +261,22 @@ def single_gpu(args):
                                "score": int(res.score), "alignment_len": int(len(res.ai)),
                                "note": "psa_align from host buffers: includes allocation, H2D and D2H"}
     out["extra"] = extra
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, b)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
     return out
 
 
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
-        from bench_multi import multi_gpu
+    if (args.gpus > 1 or world > 1) and args.mode == "stripes":
+        from bench_multi import multi_gpu   # one pair cut into column stripes (strong scaling)
         out = multi_gpu(args)
     else:
-        out = single_gpu(args)
+        out = single_gpu(args)              # independent alignments on every GPU (weak scaling)
     if out is not None:
         print(json.dumps(out))
 

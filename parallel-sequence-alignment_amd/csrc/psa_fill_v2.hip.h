@@ -182,11 +182,22 @@ __device__ __forceinline__ void lds_post(int* p, int v) {
     PSA_COMPILER_BARRIER();
 }
 
-__device__ __forceinline__ bool spin_expired(unsigned& spins, unsigned* abort_flag, unsigned limit = 1u << 25) {
+// Bounded waiting.  The bound is wall-clock time (s_memrealtime, 100 MHz), not an iteration count:
+// with several kernels or processes sharing the GPU a wait can be long in iterations without
+// anything being wrong.  Looked at once per 1024 polls, together with the abort flag (rarely:
+// hundreds of waiting waves share that one address).
+constexpr unsigned long long kSpinTicks = 30ull * 100000000ull;   // 30 s
+struct Spin {
+    unsigned n = 0;
+    unsigned long long t0 = 0;
+};
+__device__ __forceinline__ bool spin_expired(Spin& s, unsigned* abort_flag) {
     __builtin_amdgcn_s_sleep(1);
-    if ((++spins & 1023u) == 0) {   // rarely: hundreds of waiting waves share this one address
+    if ((++s.n & 1023u) == 0) {
+        const unsigned long long now = wall_clock64();
+        if (s.t0 == 0) s.t0 = now;
         const unsigned ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ab || spins > limit) {
+        if (ab || now - s.t0 > kSpinTicks) {
             __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return true;
         }
@@ -255,11 +266,11 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
             // slots t0+64..t0+79 are complete once the producer has finished step t0+78; it stops at nblocks*16
             const int need = min(t0 + 80, c.nblocks * kBlk);
             if (c.prod_seen < need) {
-                unsigned spins = 0;
+                Spin spins;
                 while ((c.prod_seen = __builtin_amdgcn_readfirstlane(lds_peek(&lds.prod[c.wv]))) < need) {
                     if (spin_expired(spins, p.abort_flag)) return false;
                 }
-                c.wait_in += spins;
+                c.wait_in += spins.n;
             }
         }
     } else if (MODE == kFast || MODE == kHead || t0 < W) {
@@ -279,7 +290,7 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
             // granules of this block were requested one block ago (a request any further ahead only
             // makes the strip settle that much further behind the one above: it runs ahead until its
             // requests start to miss); if the strip above had not published them yet, poll until it has
-            unsigned spins = 0;
+            Spin spins;
             u64 g = c.gq[JB % kGDist];
             if (MODE == kFast && IN == kInHbm) {
                 // steady state: the request is always there.  No load on the straight path, so the wait
@@ -288,7 +299,7 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
                 bool ok = !col_ok || (g >> 32) == c.tag_in;
                 if (!__all(ok)) {
                     do {
-                        if (spin_expired(spins, p.abort_flag, 1u << 22)) return false;
+                        if (spin_expired(spins, p.abort_flag)) return false;
                         g = col_ok ? load_granule(c.gin + col) : (c.tag_in << 32);
                         ok = !col_ok || (g >> 32) == c.tag_in;
                     } while (!__all(ok));
@@ -300,10 +311,10 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
                     have = false;
                     const bool ok = !col_ok || (g >> 32) == c.tag_in;
                     if (__all(ok)) break;
-                    if (spin_expired(spins, p.abort_flag, 1u << 22)) return false;
+                    if (spin_expired(spins, p.abort_flag)) return false;
                 }
             }
-            c.wait_in += spins;
+            c.wait_in += spins.n;
             gD = (int)((unsigned)g >> 2);
             gV = gD + (int)((unsigned)g & 3u);
             // request the block kGDist blocks ahead
@@ -398,11 +409,11 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
     const u32x4_a4 n1 = *(const u32x4_a4*)(c.trow + c.mword_idx + 13);
     // room in the consumer's ring for the slots this superblock writes (up to t0 + 65)
     if ((OUT == kAny) ? c.to_lds : (OUT == kOutLds)) {
-        unsigned spins = 0;
+        Spin spins;
         while (__builtin_amdgcn_readfirstlane(lds_peek(&lds.cons[c.wv + 1])) < t0 + 66 - kRing) {
             if (spin_expired(spins, p.abort_flag)) return false;
         }
-        c.wait_room += spins;
+        c.wait_room += spins.n;
     }
 #define PSA_BLOCK(j)                                                                                   \
     {                                                                                                  \
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     // goes on to poll its own granules finely.
     c.wg = __builtin_amdgcn_readfirstlane(wg_ticket);
     if (wv == 0 && c.wg >= 2 && W >= 128) {
-        unsigned spins = 0;
+        Spin spins;
         for (;;) {
             const unsigned f = __builtin_amdgcn_readfirstlane(
                 __hip_atomic_load(p.ticket + kFrontWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -552,7 +563,9 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
             const int naps = min(2 * d, 256);       // 3.4 us each; a workgroup step is 15-30 us
             for (int j = 0; j < naps; ++j) __builtin_amdgcn_s_sleep(127);
             const unsigned ab = __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ab || ++spins > (1u << 16)) {
+            const unsigned long long now = wall_clock64();
+            if (spins.t0 == 0) spins.t0 = now;
+            if (ab || now - spins.t0 > 4 * kSpinTicks) {
                 __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void fill_strips_v1(FillArgs p) {
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 255u) == 0) {
                         const unsigned ab = __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (ab || spins > (1u << 23)) {
+                        if (ab || spins > (1u << 28)) {
                             if (lane == 0) __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             return;
                         }
