@@ -13,7 +13,7 @@ column stripes, boundary columns streamed g -> g+1 with RCCL send/recv (bench_mu
 dependency chain is n + m steps long on any number of GPUs, so it buys capacity, not time, at
 2^16).  One pair alone cannot fill the GPU (its anti-diagonal
 dependency chain is n + m steps long whatever the hardware), so the job keeps --in-flight
-(default 3) independent alignments going at a time, each on its own stream with its own code
+(default 4) independent alignments going at a time, each on its own stream with its own code
 buffer; "value" is the job's throughput, "one_pair_alone" the latency of a single alignment, and
 the roofline object is the fill kernel measured alone.  Rank 0 prints ONE JSON line.
 
@@ -26,6 +26,11 @@ import json
 import os
 import sys
 import time
+
+# Every alignment in flight has a stream of its own; with HIP's default of 4 hardware queues per process
+# streams share queues, and one stream's small kernels wait behind another stream's fill.
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
+    os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -40,11 +45,11 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1)")
-    ap.add_argument("--in-flight", type=int, default=3, help="independent alignments in flight (N = 1)")
+    ap.add_argument("--in-flight", type=int, default=4, help="independent alignments in flight (N = 1)")
     ap.add_argument("--mode", choices=["pairs", "stripes"], default="pairs",
                     help="N > 1: independent pairs per GPU (default) or one pair in N column stripes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -130,9 +135,10 @@ def single_gpu(args):
         fa, fb = psa_amd.finish_alignment(ai[:ln], bj[:ln], n, m)
         return sc, len(fa)
 
-    def run_steps(count):
+    def run_steps(count, stagger_s=0.0):
         """`count` independent alignments, up to P of them in flight: one host thread, stripe object and
-        stream per slot; a slot takes the next alignment as soon as it has finished its last one."""
+        stream per slot; a slot takes the next alignment as soon as it has finished its last one.  Slot i
+        starts i * stagger_s late, so that the slots do not march in step (all filling, then all walking)."""
         lock = threading.Lock()
         state = {"next": 0}
         res, fill_ms, tb_ms = [], [], []
@@ -141,6 +147,8 @@ def single_gpu(args):
             st, stream = stripes[slot], streams[slot].cuda_stream
             ai = np.zeros(cap, np.int32)
             bj = np.zeros(cap, np.int32)
+            if slot and stagger_s > 0:
+                time.sleep(slot * stagger_s)
             while True:
                 with lock:
                     if state["next"] >= count:
@@ -155,12 +163,14 @@ def single_gpu(args):
         [x.join() for x in th]
         return res, fill_ms, tb_ms
 
-    run_steps(args.warmup)
+    run_steps(args.warmup, 0.004)
+    torch.cuda.synchronize()
+    stagger = 0.004
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res, fill_ovl, tb_ovl = run_steps(args.steps)
+    res, fill_ovl, tb_ovl = run_steps(args.steps, stagger)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -28,6 +28,7 @@ namespace psa {
 #define PSA_GDIST 2
 #endif
 constexpr int kGDist = PSA_GDIST;  // granule requests run this many blocks ahead (1, 2 or 4)
+constexpr int kKeepoutWords = 24 * 1024;   // 96 KB of LDS kept out of use, see fill_strips_v2
 constexpr int kFrontWord = 32;  // control block: [0] ticket, [1] abort flag, [32] front (own cache line)
 constexpr int kNW = 4;         // strips (wavefronts) per workgroup
 constexpr int kRing = 256;     // LDS ring slots per strip boundary (8 bytes each)
@@ -467,6 +468,11 @@ template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WAVES_PER_EU, PSA_WAVES_PER_EU))) void fill_strips_v2(FillArgs2 q) {
     __shared__ FillLds lds;
     __shared__ unsigned wg_ticket;
+    // LDS nobody uses: with it a workgroup takes more than half of a CU's 160 KB, so that no second
+    // fill workgroup and no traceback walk (64 KB) can be placed beside it.  Every strip is a link
+    // of one dependency chain: a wave that shares its SIMD's issue slots holds up the whole chain.
+    __shared__ unsigned lds_keepout[kKeepoutWords];
+    if (q.base.W < 0) { lds_keepout[threadIdx.x] = q.base.Q; __syncthreads(); q.base.ticket[2] = lds_keepout[threadIdx.x ^ 1]; }   // (never true; keeps the array allocated)
     const FillArgs& p = q.base;
     StripCtx<CODES> c;
     const int lane = c.lane = threadIdx.x & 63;

@@ -303,7 +303,8 @@ int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]) {
                                         (long long)s->next_r0, (long long)s->n);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = check_abort(s, st)) return rc;
-    HIP_TRY(hipMemcpy(triple_out, s->small + 8, 3 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(triple_out, s->small + 8, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));   // (on the stripe's own stream: the null stream would order it against other stripes' work)
     return PSA_OK;
 }
 
@@ -341,8 +342,9 @@ int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io,
     const int64_t got = state[4];
     if (*len_io + got > cap) return fail(PSA_E_ARG, "psa_stripe_traceback: output capacity %lld too small", (long long)cap);
     if (got) {
-        HIP_TRY(hipMemcpy(ai + *len_io, s->tb_ai, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(bj + *len_io, s->tb_bj, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(ai + *len_io, s->tb_ai, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(bj + *len_io, s->tb_bj, sizeof(int32_t) * (size_t)got, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
     *len_io += got;
     *i_io = state[0]; *j_io = state[1]; *k_io = (int)state[2];
