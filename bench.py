@@ -77,7 +77,7 @@ def pmc_traffic(kernel_substr, grid):
     (gfx950 correction, MI355X_MICROARCH.md, HBM section).  None when the summaries are absent."""
     import csv
     tot, src = 0.0, []
-    for name, scale in (("pmc_w_bench_2p16_b.csv", 1024.0), ("pmc_f_bench_2p16_b.csv", 2048.0)):
+    for name, scale in (("pmc_w_bench_2p16.csv", 1024.0), ("pmc_f_bench_2p16.csv", 2048.0)):
         path = os.path.join(ROOT, "profiles", "r1", name)
         if not os.path.exists(path):
             return None, None
@@ -91,6 +91,19 @@ def pmc_traffic(kernel_substr, grid):
             return None, None
         src.append("profiles/r1/" + name)
     return tot, src
+
+
+def pmc_valu_per_cell(kernel_substr, grid, cells):
+    """Executed VALU instructions per cell (SQ_INSTS_VALU x 64 lanes / cells) from the committed --pmc pass."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r1", "pmc_sq_bench_2p16.csv")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if kernel_substr in row["kernel"] and int(row["grid_size"]) == grid and row["counter"] == "SQ_INSTS_VALU":
+                return float(row["avg_value"]) * 64.0 / cells
+    return None
 
 
 def single_gpu(args):
@@ -224,7 +237,9 @@ def single_gpu(args):
                    "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
         "roofline": {"bound": "valu", "kernel": "fill_strips_v2<true> (fill with winner codes)", "achieved": achieved,
                      "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
-                     "ops_per_cell": OPS_PER_CELL_CODES, "kernel_ms": fill,
+                     "ops_per_cell": OPS_PER_CELL_CODES,
+                     "valu_insts_per_cell_executed": pmc_valu_per_cell("fill_strips_v2<true>", 65536, cells1) if k == 16 else None,
+                     "kernel_ms": fill,
                      "kernel_ms_note": "HIP events around the launch, alignment alone on the GPU (%d launches after the "
                                        "timed region); launches of the timed region overlap each other" % iso_reps,
                      "launch_ms_overlapped": fill_o, "fill_gcups": cells1 / (fill * 1e-3) / 1e9,
