@@ -285,6 +285,12 @@ def single_gpu(args):
         extra["titin_pair"] = {"gcups_end_to_end_host_buffers": len(ta) * len(tb) / dtt / 1e9, "ms": dtt * 1e3,
                                "score": int(res.score), "alignment_len": int(len(res.ai)),
                                "note": "psa_align from host buffers: includes allocation, H2D and D2H"}
+        # BASELINE config 5 shape: a block of 512-residue proteins, all queries x all targets, score only
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_batch
+        bb = bench_batch.measure(nq=2048, nt=256, L=512, reps=3, check=4)
+        bb["valu_frac"] = bb["gcups"] * OPS_PER_CELL_SCORE / 1e3 / VALU_PEAK_TOPS
+        extra["batch_512aa_score_only"] = bb
     out["extra"] = extra
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, b)

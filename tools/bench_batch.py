@@ -1,0 +1,49 @@
+"""Measure the batch score kernel (BASELINE config 5 shape: synthetic 512-aa proteins, a block of
+queries x targets, score only, everything resident in HBM).  Prints one JSON object."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch
+import psa_amd
+
+
+def measure(nq=2048, nt=256, L=512, reps=3, check=8):
+    seqs = [psa_amd.synth_protein(0xC0000000 + i, L) for i in range(max(nq, nt))]
+    flat = np.concatenate(seqs)
+    offsets = np.arange(len(seqs) + 1, dtype=np.int64) * L
+    qi, ti = np.meshgrid(np.arange(nq, dtype=np.int32), np.arange(nt, dtype=np.int32), indexing="ij")
+    pairs = np.stack([qi.ravel(), ti.ravel()], axis=1).astype(np.int32)
+    d_flat = torch.from_numpy(flat).cuda(); d_off = torch.from_numpy(offsets).cuda()
+    d_pairs = torch.from_numpy(pairs).cuda()
+    d_scores = torch.zeros(pairs.shape[0], dtype=torch.int32, device="cuda")
+    d_ctr = torch.zeros(64, dtype=torch.int32, device="cuda")
+    lib = psa_amd.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        d_ctr.zero_()
+        rc = lib.psa_score_batch_dev(d_flat.data_ptr(), d_off.data_ptr(), d_pairs.data_ptr(), pairs.shape[0], L,
+                                     d_scores.data_ptr(), d_ctr.data_ptr(), stream)
+        assert rc == 0, psa_amd.lib().psa_last_error()
+    run(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out = {"pairs": int(pairs.shape[0]), "residues": L, "ms": dt * 1e3,
+           "gcups": pairs.shape[0] * float(L) * L / dt / 1e9}
+    if check:
+        import oracle_lib as O
+        sc = d_scores.cpu().numpy()
+        rng = np.random.default_rng(5)
+        for idx in rng.integers(0, pairs.shape[0], check):
+            a, b = seqs[pairs[idx, 0]], seqs[pairs[idx, 1]]
+            assert sc[idx] == O.score(a, b), (idx, sc[idx])
+        out["checked_against_oracle"] = int(check)
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(measure()))
