@@ -137,3 +137,42 @@ def test_batch_scores_match_oracle():
     for idx in range(0, len(pairs), 37):
         i, j = pairs[idx]
         assert got[idx] == O.score(prot[i], prot[j])
+
+
+def test_alignments_in_flight_concurrently():
+    """Several whole-pair alignments at once (a host thread each, the library's per-call streams),
+    as the bench's throughput mode does: results stay those of the oracle."""
+    import threading
+    rng = np.random.default_rng(11)
+    pairs = []
+    for k in range(4):
+        n, m = int(rng.integers(3000, 6000)), int(rng.integers(3000, 6000))
+        pairs.append((rng.integers(65, 69, n).astype(np.uint8), rng.integers(65, 69, m).astype(np.uint8)))
+    want = [O.align(a, b) for a, b in pairs]
+    got = [None] * len(pairs)
+
+    def work(i):
+        for _ in range(3):
+            got[i] = psa_amd.align(pairs[i][0], pairs[i][1], 1)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(pairs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for (sc, ai, bj), res in zip(want, got):
+        assert res is not None and res.score == sc
+        assert np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj)
+
+
+def test_traceback_kernels_agree(monkeypatch):
+    """The wave-cooperative walk and the single-lane walk read the same packed codes."""
+    rng = np.random.default_rng(12)
+    a = rng.integers(65, 69, 2500).astype(np.uint8)
+    b = rng.integers(65, 69, 2700).astype(np.uint8)
+    r1 = psa_amd.align(a, b, 1)
+    monkeypatch.setenv("PSA_TRACEBACK_KERNEL", "v1")
+    r2 = psa_amd.align(a, b, 1)
+    monkeypatch.setenv("PSA_FILL_KERNEL", "v1")
+    r3 = psa_amd.align(a, b, 1)
+    sc, ai, bj = O.align(a, b)
+    for r in (r1, r2, r3):
+        assert r.score == sc and np.array_equal(r.ai, ai) and np.array_equal(r.bj, bj)
