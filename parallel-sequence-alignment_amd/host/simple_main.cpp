@@ -4,8 +4,10 @@
 // result lines go to stdout, exit status 0 even when a file is missing (the reader then yields
 // an empty sequence).  The alignment itself runs on the GPU through the C ABI of include/psa.h;
 // there is no CPU path, so without a usable device the program reports the error and exits 3.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <string>
 
@@ -37,6 +39,32 @@ int main(int argc, char* argv[]) {
     char* text = psa_format_result(score, a, b, ai, bj, len, &out_len);
     fwrite(text, 1, (size_t)out_len, stdout);
     fflush(stdout);
-    psa_free(text); psa_free(ai); psa_free(bj); psa_free(a); psa_free(b);
+    psa_free(text); psa_free(ai); psa_free(bj);
+
+    // The reference's timing sweep (commented out in simple.cpp:319-335): p = 1..32, one line per p on
+    // stdout and "threads,time_microseconds" rows in a CSV.  Off unless PSA_TIMINGS_CSV names the file,
+    // so that the default output stays the reference's five lines.
+    if (const char* csv_path = std::getenv("PSA_TIMINGS_CSV")) {
+        std::ofstream csv(csv_path);
+        csv << "threads,time_microseconds\n";
+        for (int q = 1; q <= 32; ++q) {
+            const auto start = std::chrono::high_resolution_clock::now();
+            int32_t sc = 0, *xi = nullptr, *xj = nullptr;
+            int64_t xl = 0;
+            const int rq = psa_align(a, n, b, m, q, &sc, &xi, &xj, &xl);
+            const auto end = std::chrono::high_resolution_clock::now();
+            if (rq != PSA_OK) {
+                std::cerr << "simple: " << psa_last_error() << " (code " << rq << ")\n";
+                return 3;
+            }
+            psa_free(xi); psa_free(xj);
+            const auto us = std::chrono::duration_cast<std::chrono::microseconds>(end - start).count();
+            std::cout << "p=" << q << ", time=" << us << " \xC2\xB5s, score=" << sc << std::endl;
+            csv << q << "," << us << "\n";
+        }
+        csv.close();
+        std::cout << "Timing results written to " << csv_path << "\n";
+    }
+    psa_free(a); psa_free(b);
     return 0;
 }

@@ -120,6 +120,24 @@ def test_cli_byte_exact(golden_dir):
     assert r.returncode == 1 and b"Usage:" in r.stderr and r.stdout == b""
 
 
+def test_cli_timing_sweep(golden_dir, tmp_path):
+    """The reference's (commented-out) p = 1..32 sweep, simple.cpp:319-335: same CSV header and rows."""
+    exe = os.path.join(ROOT, "simple")
+    c = O.load_golden("ref_fasta_pairs.json")[0]
+    csv = tmp_path / "timings.csv"
+    env = dict(os.environ, PSA_TIMINGS_CSV=str(csv))
+    r = subprocess.run([exe, c["a"], c["b"], "1"], cwd=golden_dir, capture_output=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    gold = O.b64d(c["stdout_b64"])
+    assert r.stdout.startswith(gold)
+    score = gold.split(b"\n")[0].split(b": ")[1]
+    lines = r.stdout[len(gold):].decode().splitlines()
+    assert len(lines) == 33 and all(l.startswith("p=%d, time=" % (k + 1)) and l.endswith("score=" + score.decode())
+                                    for k, l in enumerate(lines[:32]))
+    rows = csv.read_text().splitlines()
+    assert rows[0] == "threads,time_microseconds" and [x.split(",")[0] for x in rows[1:]] == [str(k) for k in range(1, 33)]
+
+
 def test_batch_scores_match_oracle():
     rng = np.random.default_rng(23)
     seqs = []
