@@ -155,6 +155,15 @@ int64_t psa_stripe_code_bytes(const psa_stripe* s);
  * after printing the reference's message on stderr). */
 uint8_t* psa_read_fasta(const char* path, int64_t* len_out);
 
+/* Batch input (no counterpart in the reference, which concatenates all records of a
+ * file into one sequence, read_fasta.cpp:16-19): the same line handling as psa_read_fasta, but
+ * every '>' header line starts a new record.  *seqs_out = all residues back to back,
+ * (*offsets_out)[r] .. [r+1] = record r, *nrec_out records; the layout psa_score_batch takes.
+ * Residues before the first header form record 0 (so that the concatenation of all records always
+ * equals what psa_read_fasta returns).  Both buffers are released with psa_free().  Returns PSA_OK
+ * or PSA_E_ARG (file cannot be opened; the reference's message goes to stderr). */
+int psa_read_fasta_records(const char* path, uint8_t** seqs_out, int64_t** offsets_out, int64_t* nrec_out);
+
 /* Synthetic iid-uniform protein over ACDEFGHIKLMNPQRSTVWY: out[k] = alphabet[g() % 20] with
  * std::mt19937_64 g(seed).  Host-side. */
 void psa_synth_protein(uint64_t seed, int64_t n, uint8_t* out);

@@ -20,6 +20,7 @@ from .binding import (  # noqa: F401
     lib_path,
     pick,
     read_fasta,
+    read_fasta_records,
     run,
     score,
     score_batch,

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "psa_stripe_last_traceback_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "psa_stripe_code_bytes": (_i64, [C.c_void_p]),
     "psa_read_fasta": (C.c_void_p, [C.c_char_p, _i64p]),
+    "psa_read_fasta_records": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i64p]),
     "psa_synth_protein": (None, [C.c_uint64, _i64, C.c_void_p]),
 }
 
@@ -185,6 +186,19 @@ def read_fasta(path):
         return C.string_at(p, n.value)
     finally:
         lib().psa_free(p)
+
+
+def read_fasta_records(path):
+    """Every '>' record of a FASTA file as its own byte string (psa_read_fasta_records): batch input."""
+    seqs, offs, n = C.c_void_p(), C.c_void_p(), _i64()
+    _check(lib().psa_read_fasta_records(os.fsencode(path), C.byref(seqs), C.byref(offs), C.byref(n)))
+    try:
+        off = np.ctypeslib.as_array(C.cast(offs, C.POINTER(C.c_int64)), shape=(n.value + 1,)).copy()
+        flat = C.string_at(seqs, int(off[-1]))
+        return [flat[off[r]:off[r + 1]] for r in range(n.value)]
+    finally:
+        lib().psa_free(seqs)
+        lib().psa_free(offs)
 
 
 def synth_protein(seed, n):

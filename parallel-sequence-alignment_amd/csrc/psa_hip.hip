@@ -615,6 +615,42 @@ uint8_t* psa_read_fasta(const char* path, int64_t* len_out) {
     return buf;
 }
 
+int psa_read_fasta_records(const char* path, uint8_t** seqs_out, int64_t** offsets_out, int64_t* nrec_out) {
+    if (!seqs_out || !offsets_out || !nrec_out) return fail(PSA_E_ARG, "psa_read_fasta_records: null argument");
+    *seqs_out = nullptr; *offsets_out = nullptr; *nrec_out = 0;
+    FILE* f = path ? fopen(path, "rb") : nullptr;
+    if (!f) {
+        fprintf(stderr, "Error opening file: %s\n", path ? path : "(null)");
+        return fail(PSA_E_ARG, "psa_read_fasta_records: cannot open %s", path ? path : "(null)");
+    }
+    std::string seq, line;
+    std::vector<int64_t> starts;   // offset at which each record begins
+    int ch;
+    bool any = false;
+    auto flush = [&]() {
+        if (!line.empty() && line[0] == '>') starts.push_back((int64_t)seq.size());
+        else if (!line.empty()) {
+            if (starts.empty()) starts.push_back(0);   // residues before any header: record 0
+            seq += line;
+        }
+        line.clear();
+    };
+    while ((ch = fgetc(f)) != EOF) {
+        any = true;
+        if (ch == '\n') flush(); else line.push_back((char)ch);
+    }
+    if (any) flush();
+    fclose(f);
+    uint8_t* buf = (uint8_t*)malloc(seq.size() + 1);
+    int64_t* off = (int64_t*)malloc(sizeof(int64_t) * (starts.size() + 1));
+    if (!buf || !off) { free(buf); free(off); return fail(PSA_E_ARG, "psa_read_fasta_records: out of memory"); }
+    memcpy(buf, seq.data(), seq.size());
+    for (size_t r = 0; r < starts.size(); ++r) off[r] = starts[r];
+    off[starts.size()] = (int64_t)seq.size();
+    *seqs_out = buf; *offsets_out = off; *nrec_out = (int64_t)starts.size();
+    return PSA_OK;
+}
+
 void psa_synth_protein(uint64_t seed, int64_t n, uint8_t* out) {
     static const char alphabet[] = "ACDEFGHIKLMNPQRSTVWY";
     std::mt19937_64 g(seed);

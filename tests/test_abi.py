@@ -46,6 +46,17 @@ def test_fasta_reader_matches_reference_behaviour(tmp_path):
                 continue
             path.write_bytes(base64.b64decode(c[key]))
             assert psa_amd.read_fasta(str(path)) == O.read_fasta(str(path))
+            # the record-wise reader sees the same residues, cut at the header lines
+            assert b"".join(psa_amd.read_fasta_records(str(path))) == O.read_fasta(str(path))
+
+
+def test_fasta_records(tmp_path):
+    path = tmp_path / "multi.fasta"
+    path.write_bytes(b"ACD\n>r1 first\nEFG\nHIK\n>r2\n\n>r3\nLMN")
+    assert psa_amd.read_fasta_records(str(path)) == [b"ACD", b"EFGHIK", b"", b"LMN"]
+    assert psa_amd.read_fasta(str(path)) == b"ACDEFGHIKLMN"
+    with pytest.raises(psa_amd.PsaError):
+        psa_amd.read_fasta_records(str(tmp_path / "missing.fasta"))
 
 
 def test_format_and_finish_match_oracle():
