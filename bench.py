@@ -124,8 +124,17 @@ def single_gpu(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)          # the first collective builds the communicator: fail here, not mid-run
+                torch.cuda.synchronize()
+            except Exception as e:              # the barrier is all this mode needs: fall back to gloo
+                print("bench: nccl unavailable (%s), timing barrier over gloo" % e, file=sys.stderr)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = "gloo"
+        if backend != "nccl":
             dist.init_process_group(backend, rank=rank, world_size=world)
     k = args.log2n
     n = m = 1 << k
