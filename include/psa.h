@@ -37,6 +37,7 @@ extern "C" {
 #define PSA_E_STATE (-6)      /* calls made in the wrong order */
 
 #define PSA_F_TRACEBACK 1u    /* keep packed winner codes in HBM so an alignment can be rebuilt */
+#define PSA_F_BANDED 2u       /* with PSA_F_TRACEBACK: codes for one band of rows at a time (psa_align_banded) */
 
 const char* psa_last_error(void);
 const char* psa_version(void);
@@ -147,6 +148,16 @@ int psa_stripe_last_fill_ms(psa_stripe* s, float* ms_out);
 int psa_stripe_last_traceback_ms(psa_stripe* s, float* ms_out);
 /* Bytes of packed winner codes this stripe writes per full fill (the traceback stream). */
 int64_t psa_stripe_code_bytes(const psa_stripe* s);
+
+/* run() in linear space (the idea complex.cpp:193-689 attempts): same result as
+ * psa_align, but the winner codes of only `band_rows` rows (a multiple of 64; 0 = chosen so that
+ * they take about 8 GB) exist at any time.  Pass 1 fills score-only and keeps the hand-off row in
+ * front of every band (8 bytes per column and band); pass 2 goes through the bands bottom-up,
+ * refills one band with codes -- only the columns left of where the walk enters it -- and walks it.
+ * About twice the work of psa_align, for pairs whose codes (0.75 byte per cell) do not fit in HBM.
+ * psa_align switches to it by itself when they do not, or when PSA_BAND_ROWS is set. */
+int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int64_t band_rows,
+                     int32_t* score_out, int32_t** ai_out, int32_t** bj_out, int64_t* len_out);
 
 /* ---- helpers shared with the command-line front end ------------------------------------ */
 

@@ -33,6 +33,8 @@ _SIGNATURES = {
     "psa_free": (None, [C.c_void_p]),
     "psa_align": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, C.c_int, _i32p, C.POINTER(C.c_void_p),
                             C.POINTER(C.c_void_p), _i64p]),
+    "psa_align_banded": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, _i64, _i32p, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_void_p), _i64p]),
     "psa_score": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, C.c_int, _i32p, _i32p]),
     "psa_score_batch": (C.c_int, [C.c_void_p, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p]),
     "psa_score_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_int, C.c_void_p, C.c_void_p,
@@ -107,13 +109,18 @@ def pick(t1, t2, t3):
     return 3, t3
 
 
-def align(a, b, p=1):
-    """run(p, A, B) of the reference (simple.cpp:261): returns Result(score, ai, bj)."""
+def align(a, b, p=1, band_rows=None):
+    """run(p, A, B) of the reference (simple.cpp:261): returns Result(score, ai, bj).  band_rows (a multiple
+    of 64, or 0 for the library's choice) selects the linear-space variant psa_align_banded."""
     a, b = _seq(a), _seq(b)
     score = _i32()
     ai, bj, n = C.c_void_p(), C.c_void_p(), _i64()
-    _check(lib().psa_align(_ptr(a), a.size, _ptr(b), b.size, int(p), C.byref(score), C.byref(ai), C.byref(bj),
-                           C.byref(n)))
+    if band_rows is None:
+        _check(lib().psa_align(_ptr(a), a.size, _ptr(b), b.size, int(p), C.byref(score), C.byref(ai), C.byref(bj),
+                               C.byref(n)))
+    else:
+        _check(lib().psa_align_banded(_ptr(a), a.size, _ptr(b), b.size, int(band_rows), C.byref(score), C.byref(ai),
+                                      C.byref(bj), C.byref(n)))
     try:
         if n.value:
             xa = np.ctypeslib.as_array(C.cast(ai, _i32p), shape=(n.value,)).copy()

@@ -57,6 +57,16 @@ int pick3(const int32_t t[3], int32_t* v) {
 
 constexpr size_t kCtrlBytes = 256;
 
+// rows per band in banded mode: PSA_BAND_ROWS, else as many strips as 8 GiB of codes hold
+int64_t g_band_rows_request = 0;   // set by psa_align_banded around the stripe's creation
+int64_t band_rows_for(int64_t n, int Q) {
+    int64_t want = g_band_rows_request;
+    if (want <= 0) if (const char* e = getenv("PSA_BAND_ROWS")) want = atoll(e);
+    if (want <= 0) want = 64 * std::max<int64_t>(1, (8LL << 30) / ((int64_t)Q * 3072));
+    want = std::max<int64_t>(64, (want / 64) * 64);
+    return std::min<int64_t>(want, ((n + 63) / 64) * 64);
+}
+
 }  // namespace
 
 struct psa_stripe {
@@ -85,7 +95,23 @@ struct psa_stripe {
     unsigned nsym = 0;
     bool use_v2 = false;
     bool fill_timed = false, tb_timed = false;
+    // banded (linear-space) mode: codes cover band_rows rows at a time, ckpt holds the hand-off ring as it
+    // was before each band (see align_banded)
+    int64_t band_rows = 0;
+    psa::u64* ckpt = nullptr;
 };
+
+namespace {
+// what one fill launch may override (banded mode)
+struct FillOpts {
+    int codes = -1;                  // -1: as the stripe was created; 0 / 1: without / with winner codes
+    int W = 0;                       // > 0: only the stripe's first W columns
+    uint32_t* codes_base = nullptr;  // where strip 0's codes would lie
+    bool any_order = false;          // do not insist on r0 == end of the previous chunk
+};
+int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev, void* stream,
+                   const FillOpts& o);
+}  // namespace
 
 namespace {
 
@@ -140,6 +166,7 @@ void psa_stripe_destroy(psa_stripe* s) {
     if (!s) return;
     hipFree(s->a_dev); hipFree(s->b_dev); hipFree(s->ring); hipFree(s->codes);
     hipFree(s->a_ids); hipFree(s->alpha); hipFree(s->eqtab);
+    hipFree(s->ckpt);
     hipFree(s->small); hipFree(s->ctrl); hipFree(s->tb_ai); hipFree(s->tb_bj); hipFree(s->tb_state);
     for (auto& e : s->ev) if (e) hipEventDestroy(e);
     delete s;
@@ -177,7 +204,14 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
     CREATE_TRY(hipMalloc(&s->small, 64));
     CREATE_TRY(hipMalloc(&s->ctrl, kCtrlBytes));
     if (flags & PSA_F_TRACEBACK) {
-        s->code_bytes = (size_t)strips * (size_t)s->Q * 3 * 64 * 4 * sizeof(uint32_t);
+        int64_t code_strips = strips;
+        if (flags & PSA_F_BANDED) {
+            s->band_rows = band_rows_for(n, s->Q);
+            code_strips = s->band_rows / 64;
+            const int64_t nbands = (n + s->band_rows - 1) / s->band_rows;
+            CREATE_TRY(hipMalloc(&s->ckpt, sizeof(psa::u64) * (size_t)nbands * (2 * (size_t)s->Wpad + 64)));
+        }
+        s->code_bytes = (size_t)code_strips * (size_t)s->Q * 3 * 64 * 4 * sizeof(uint32_t);
         CREATE_TRY(hipMalloc(&s->codes, s->code_bytes));
         s->tb_cap = n + s->W + 2;
         CREATE_TRY(hipMalloc(&s->tb_ai, sizeof(int32_t) * (size_t)s->tb_cap));
@@ -205,8 +239,18 @@ int psa_stripe_set_sequences_dev(psa_stripe* s, const uint8_t* a_dev, const uint
 
 int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev,
                          void* stream) {
+    if (s && s->band_rows) return fail(PSA_E_STATE, "psa_stripe_fill_rows: a banded stripe is driven by psa_align_banded");
+    return fill_rows_impl(s, r0, r1, left_dev, right_dev, stream, FillOpts());
+}
+
+}  // extern "C"
+
+namespace {
+int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev, void* stream,
+                   const FillOpts& o) {
     if (!s) return fail(PSA_E_ARG, "psa_stripe_fill_rows: null stripe");
     if (r0 == 0) s->next_r0 = 0;  // a new pass over the same stripe
+    if (o.any_order) s->next_r0 = r0;
     if (r0 != s->next_r0) return fail(PSA_E_STATE, "psa_stripe_fill_rows: chunks out of order (r0=%lld, expected %lld)",
                                       (long long)r0, (long long)s->next_r0);
     if ((r0 & 63) || r1 <= r0 || r1 > s->n)
@@ -222,14 +266,15 @@ int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* l
     HIP_TRY(hipMemsetAsync(s->ctrl, 0, kCtrlBytes, st));
     psa::FillArgs fa;
     fa.a = s->a_dev; fa.b = s->b_dev; fa.n = s->n; fa.r0 = r0; fa.r1 = r1; fa.c0 = s->c0;
-    fa.W = s->W; fa.Q = s->Q; fa.Wpad = s->Wpad;
+    fa.W = o.W > 0 ? o.W : s->W; fa.Q = o.W > 0 ? (o.W + 63 + 63) / 64 : s->Q; fa.Wpad = s->Wpad;
+    const bool with_codes = o.codes < 0 ? s->codes != nullptr : o.codes != 0;
     fa.left = left_dev;
     fa.corner = s->small + 4 * s->corner_cur;
     fa.corner_next = s->small + 4 * (s->corner_cur ^ 1);
     fa.right = right_dev;
     fa.final_triple = s->small + 8;
     fa.ring = s->ring;
-    fa.codes = s->codes;
+    fa.codes = with_codes ? (o.codes_base ? o.codes_base : s->codes) : nullptr;
     fa.ticket = s->ctrl;
     fa.abort_flag = s->ctrl + 1;
     fa.prof = nullptr;
@@ -249,9 +294,9 @@ int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* l
         psa::FillArgs2 fb;
         fb.base = fa; fb.a_ids = s->a_ids; fb.eqtab = s->eqtab; fb.tab_pitch = s->tab_pitch;
         const unsigned wgs = (strips + psa::kNW - 1) / psa::kNW;
-        if (s->codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(wgs), dim3(psa::kNW * 64), 0, st, fb);
+        if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(wgs), dim3(psa::kNW * 64), 0, st, fb);
         else hipLaunchKernelGGL(psa::fill_strips_v2<false>, dim3(wgs), dim3(psa::kNW * 64), 0, st, fb);
-    } else if (s->codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fa);
+    } else if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fa);
     else hipLaunchKernelGGL(psa::fill_strips_v1<false>, dim3(strips), dim3(64), 0, st, fa);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], st));
@@ -288,6 +333,9 @@ int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* l
     s->next_r0 = r1;
     return PSA_OK;
 }
+}  // namespace
+
+extern "C" {
 
 static int check_abort(psa_stripe* s, hipStream_t st) {
     unsigned ctrl[2] = {0, 0};
@@ -308,11 +356,34 @@ int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]) {
     return PSA_OK;
 }
 
+}  // extern "C"
+
+namespace {
+struct TraceOpts {
+    const uint32_t* codes_base = nullptr;   // banded mode: where strip 0's codes would lie
+    int W = 0;                              // > 0: the codes were written by a fill of the first W columns
+    int64_t row_min = 0;                    // the codes cover rows > row_min only
+};
+int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai, int32_t* bj,
+                   int64_t cap, int64_t* len_io, void* stream, const TraceOpts& o);
+}  // namespace
+
+extern "C" {
+
 int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai, int32_t* bj,
                          int64_t cap, int64_t* len_io, void* stream) {
+    if (s && s->band_rows) return fail(PSA_E_STATE, "psa_stripe_traceback: a banded stripe is driven by psa_align_banded");
+    if (s && s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_traceback: fill is not complete");
+    return traceback_impl(s, i_io, j_io, k_io, ai, bj, cap, len_io, stream, TraceOpts());
+}
+
+}  // extern "C"
+
+namespace {
+int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai, int32_t* bj,
+                   int64_t cap, int64_t* len_io, void* stream, const TraceOpts& o) {
     if (!s || !i_io || !j_io || !k_io || !ai || !bj || !len_io) return fail(PSA_E_ARG, "psa_stripe_traceback: null argument");
     if (!s->codes) return fail(PSA_E_STATE, "psa_stripe_traceback: stripe was created without PSA_F_TRACEBACK");
-    if (s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_traceback: fill is not complete");
     if (*k_io < 1 || *k_io > 3 || *i_io < 0 || *i_io > s->n || *j_io < 0 || *j_io > s->c1 + 1)
         return fail(PSA_E_ARG, "psa_stripe_traceback: bad state (%lld,%lld,%d)", (long long)*i_io, (long long)*j_io, *k_io);
     hipStream_t st = (hipStream_t)stream;
@@ -320,14 +391,16 @@ int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io,
     int64_t state[12] = {*i_io, *j_io, *k_io, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(s->tb_state, state, sizeof state, hipMemcpyHostToDevice, st));
     psa::TraceArgs ta;
-    ta.codes = s->codes; ta.c0 = s->c0; ta.W = s->W; ta.Q = s->Q; ta.cap = s->tb_cap;
+    ta.codes = o.codes_base ? o.codes_base : s->codes; ta.c0 = s->c0; ta.cap = s->tb_cap;
+    ta.W = o.W > 0 ? o.W : s->W; ta.Q = o.W > 0 ? (o.W + 63 + 63) / 64 : s->Q;
+    ta.row_min = o.row_min;
     ta.out_ai = s->tb_ai; ta.out_bj = s->tb_bj; ta.state = s->tb_state;
     HIP_TRY(hipEventRecord(s->ev[2], st));
     {
         const char* force = getenv("PSA_TRACEBACK_KERNEL");
         // the fast kernels keep the walk in 32-bit registers: coordinates and tile ids must fit
         const bool fits32 = s->n < 0x7fff0000LL && s->c0 + s->W < 0x7fff0000LL &&
-                            ((s->n + 63) / 64) * (int64_t)s->Q < 0x7fff0000LL;
+                            ((s->n + 63) / 64) * (int64_t)ta.Q < 0x7fff0000LL;
         if ((force && !strcmp(force, "v1")) || !fits32) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
         else hipLaunchKernelGGL(psa::traceback_wave, dim3(1), dim3(64), 0, st, ta);
     }
@@ -348,9 +421,13 @@ int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io,
     }
     *len_io += got;
     *i_io = state[0]; *j_io = state[1]; *k_io = (int)state[2];
-    if (!state[3] && s->c0 == 0) return fail(PSA_E_KERNEL, "traceback: head stripe stopped before the matrix boundary");
+    if (!state[3] && s->c0 == 0 && o.row_min == 0)
+        return fail(PSA_E_KERNEL, "traceback: head stripe stopped before the matrix boundary");
     return PSA_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int psa_stripe_last_fill_ms(psa_stripe* s, float* ms_out) {
     if (!s || !ms_out || !s->fill_timed) return fail(PSA_E_STATE, "no fill has been timed");
@@ -464,6 +541,15 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, i
     *ai_out = *bj_out = nullptr;
     *len_out = 0;
     const int64_t cap = 2 * (n + m) + 2;
+    if (n > 0 && m > 0) {
+        // codes of the whole matrix (0.75 B per cell) against what the device has free: beyond 70 %
+        // of it -- or when PSA_BAND_ROWS asks for it -- align in linear space
+        size_t free_b = 0, total_b = 0;
+        const double code_bytes = 0.75 * (double)n * (double)m;
+        const bool forced = getenv("PSA_BAND_ROWS") != nullptr;
+        if (forced || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && code_bytes > 0.7 * (double)free_b))
+            return psa_align_banded(a, n, b, m, 0, score_out, ai_out, bj_out, len_out);
+    }
     int32_t* ai = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
     int32_t* bj = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
     if (!ai || !bj) { free(ai); free(bj); return fail(PSA_E_NOMEM, "psa_align: host allocation failed"); }
@@ -488,6 +574,69 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, i
     if (rc == PSA_OK) rc = psa_finish_alignment(ai, bj, len, cap, &len);
     if (rc != PSA_OK) { free(ai); free(bj); return rc; }
     pick3(t, score_out);
+    *ai_out = ai; *bj_out = bj; *len_out = len;
+    return PSA_OK;
+}
+
+// Linear-space alignment: see include/psa.h.  One stripe (results do not depend on p).
+int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int64_t band_rows,
+                     int32_t* score_out, int32_t** ai_out, int32_t** bj_out, int64_t* len_out) {
+    if (!score_out || !ai_out || !bj_out || !len_out || n < 1 || m < 1 || !a || !b)
+        return fail(PSA_E_ARG, "psa_align_banded: bad argument (needs n, m >= 1)");
+    if (band_rows < 0 || (band_rows & 63)) return fail(PSA_E_ARG, "psa_align_banded: band_rows must be a multiple of 64");
+    if (int rc = need_device()) return rc;
+    *ai_out = *bj_out = nullptr;
+    *len_out = 0;
+    psa_stripe* s = nullptr;
+    g_band_rows_request = band_rows;
+    int rc = psa_stripe_create(&s, a, n, b, m, 0, m, PSA_F_TRACEBACK | PSA_F_BANDED);
+    g_band_rows_request = 0;
+    if (rc) return rc;
+    StripeSet owner;
+    owner.st.push_back(s);
+    const int64_t B = s->band_rows;
+    const int64_t nbands = (n + B - 1) / B;
+    const size_t ring_words = 2 * (size_t)s->Wpad + 64;
+    // pass 1: score only; the hand-off ring as it stands before every band is kept
+    for (int64_t bnd = 0; bnd < nbands; ++bnd) {
+        const int64_t r0 = bnd * B, r1 = std::min(n, r0 + B);
+        if (bnd) HIP_TRY(hipMemcpyAsync(s->ckpt + (size_t)bnd * ring_words, s->ring, sizeof(psa::u64) * ring_words,
+                                        hipMemcpyDeviceToDevice, nullptr));
+        FillOpts fo;
+        fo.codes = 0;
+        if ((rc = fill_rows_impl(s, r0, r1, nullptr, nullptr, nullptr, fo))) return rc;
+    }
+    int32_t t[3];
+    if ((rc = psa_stripe_final(s, nullptr, t))) return rc;
+    const int64_t cap = 2 * (n + m) + 2;
+    int32_t* ai = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+    int32_t* bj = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+    if (!ai || !bj) { free(ai); free(bj); return fail(PSA_E_NOMEM, "psa_align_banded: host allocation failed"); }
+    int32_t v;
+    int64_t i = n, j = m, len = 0;
+    int k = pick3(t, &v);
+    // pass 2: bottom band first; refill with codes the columns the walk can still reach, walk, hand on
+    for (int64_t bnd = (i - 1) / B; bnd >= 0 && i > 0 && j > 0 && rc == PSA_OK; --bnd) {
+        const int64_t r0 = bnd * B, r1 = std::min(n, r0 + B);
+        if (i - (k != 2) <= r0) continue;                      // the walk left this band without a step in it
+        const int Wr = (int)std::min<int64_t>(s->W, j);
+        const int Qr = (Wr + 63 + 63) / 64;
+        uint32_t* base = (uint32_t*)((uintptr_t)s->codes -
+                                     sizeof(uint32_t) * (uintptr_t)psa::code_word_index(r0 / 64, Qr, 0, 0, 0, 0));
+        if (bnd) rc = hipMemcpyAsync(s->ring, s->ckpt + (size_t)bnd * ring_words, sizeof(psa::u64) * ring_words,
+                                     hipMemcpyDeviceToDevice, nullptr) == hipSuccess ? PSA_OK
+                                                                                       : fail(PSA_E_HIP, "restoring a band's hand-off row failed");
+        if (rc) break;
+        FillOpts fo;
+        fo.codes = 1; fo.W = Wr; fo.codes_base = base; fo.any_order = true;
+        if ((rc = fill_rows_impl(s, r0, r1, nullptr, nullptr, nullptr, fo))) break;
+        TraceOpts to;
+        to.codes_base = base; to.W = Wr; to.row_min = r0;
+        rc = traceback_impl(s, &i, &j, &k, ai, bj, cap, &len, nullptr, to);
+    }
+    if (rc == PSA_OK) rc = psa_finish_alignment(ai, bj, len, cap, &len);
+    if (rc != PSA_OK) { free(ai); free(bj); return rc; }
+    *score_out = v;
     *ai_out = ai; *bj_out = bj; *len_out = len;
     return PSA_OK;
 }

@@ -198,6 +198,8 @@ struct TraceArgs {
     int32_t* out_ai;     // columns in walk (reverse) order
     int32_t* out_bj;
     int64_t* state;      // in: i, j, k ; out: i, j, k, done (1 = reached the matrix boundary), len, error
+    int64_t row_min;     // banded mode: the codes at hand cover rows > row_min only (0: whole matrix);
+                         // `codes` then points row_min/64 strips before the band's first tile
 };
 
 __global__ __launch_bounds__(64) void traceback_v1(TraceArgs p) {
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(64) void traceback_v1(TraceArgs p) {
         if (i == 0 || j == 0) { done = 1; break; }
         const int64_t pi = i - (k != 2), pj = j - (k != 3);
         if (c0 > 0 && pj <= c0) break;  // predecessor belongs to the stripe on the left
+        if (p.row_min > 0 && pi <= p.row_min) break;  // ... or to the band of rows above
         int w;
         if (pi == 0 || pj == 0) {
             int t1, t2, t3;
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(64) void traceback_wave(TraceArgs p) {
     int k = __builtin_amdgcn_readfirstlane((int)p.state[2]);
     const int c0 = (int)p.c0;
     const int Q = p.Q;
+    const int rmin = (int)p.row_min;
     const int cap = (int)(p.cap < 0x1fffff00 ? p.cap : 0x1fffff00);   // 4 * cap fits the buffer descriptor
     int len = 0, done = 0, err = 0;
     int my_tile = -1, my_ops = 0;          // lanes 0..15: directory of the LDS slots (tile id, op count after its fetch)
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(64) void traceback_wave(TraceArgs p) {
         ++n_iter;
         const int pi = i - (k != 2), pj = j - (k != 3);
         if (c0 > 0 && pj <= c0) break;  // predecessor belongs to the stripe on the left
+        if (pi <= rmin && rmin > 0) break;   // ... or to the band of rows above
         if (pi == 0 || pj == 0) {
             int t1, t2, t3;
             boundary_triple(pi, pj, t1, t2, t3);
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(64) void traceback_wave(TraceArgs p) {
                 const int s1 = ((bt & 63) >> 1) + 1, s2 = bl + 1;
                 cpi -= s1 < s2 ? s1 : s2;          // first cell of the next tile on the diagonal
                 const int nj = cpi - diag;
-                if (cpi < 1 || nj < c0 + 1) { cpi = 0; break; }
+                if (cpi <= rmin || nj < c0 + 1) { cpi = 0; break; }   // (rows <= rmin: no codes at hand)
                 const int nl = (cpi - 1) & 63;
                 const int Tn = ((cpi - 1) >> 6) * Q + (((nj - c0 - 1) + nl) >> 6);
                 if (lookup(Tn) < 0) issue(Tn);
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(64) void traceback_wave(TraceArgs p) {
                 gi -= (w != 2); gj -= (w != 3);
                 TB_MARK(3)
             }
-        } while (ll >= 0 && tl >= 0 && gj > c0 && gi >= 1);
+        } while (ll >= 0 && tl >= 0 && gj > c0 && gi > rmin);
         if (err) break;
         i = gi + (k != 2); j = gj + (k != 3);
     }

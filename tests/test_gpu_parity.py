@@ -194,3 +194,34 @@ def test_traceback_kernels_agree(monkeypatch):
     sc, ai, bj = O.align(a, b)
     for r in (r1, r2, r3):
         assert r.score == sc and np.array_equal(r.ai, ai) and np.array_equal(r.bj, bj)
+
+
+@pytest.mark.parametrize("band", [64, 128, 320])
+def test_banded_linear_space_alignment(band):
+    """psa_align_banded (codes of one band of rows at a time) against the oracle: sizes that
+    are no multiple of the band, alphabets with long runs and long gaps, a pair shorter than a band."""
+    rng = np.random.default_rng(100 + band)
+    cases = []
+    for n, m, alpha in ((700, 650, 4), (513, 1200, 2), (1300, 300, 20), (50, 40, 3), (1000, 1000, 4)):
+        cases.append((rng.integers(65, 65 + alpha, n).astype(np.uint8), rng.integers(65, 65 + alpha, m).astype(np.uint8)))
+    x = rng.integers(65, 69, 900).astype(np.uint8)
+    cases.append((x, np.concatenate([x[:300], x[500:]])))            # one long gap
+    cases.append((np.concatenate([x[:200], x[650:]]), x))
+    for a, b in cases:
+        res = psa_amd.align(a, b, 1, band_rows=band)
+        sc, ai, bj = O.align(a, b)
+        assert res.score == sc, (a.size, b.size)
+        assert np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (a.size, b.size)
+
+
+def test_banded_through_env_and_large(monkeypatch):
+    """PSA_BAND_ROWS switches psa_align itself; a 6000 x 7000 pair with 1024-row bands equals the plain path."""
+    rng = np.random.default_rng(77)
+    a = rng.integers(65, 69, 6000).astype(np.uint8)
+    b = rng.integers(65, 69, 7000).astype(np.uint8)
+    plain = psa_amd.align(a, b, 1)
+    monkeypatch.setenv("PSA_BAND_ROWS", "1024")
+    banded = psa_amd.align(a, b, 3)
+    assert plain.score == banded.score and np.array_equal(plain.ai, banded.ai) and np.array_equal(plain.bj, banded.bj)
+    sc, ai, bj = O.align(a, b)
+    assert banded.score == sc and np.array_equal(banded.ai, ai) and np.array_equal(banded.bj, bj)
