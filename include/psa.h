@@ -150,9 +150,9 @@ int psa_stripe_last_traceback_ms(psa_stripe* s, float* ms_out);
 int64_t psa_stripe_code_bytes(const psa_stripe* s);
 
 /* run() in linear space (the idea complex.cpp:193-689 attempts): same result as
- * psa_align, but the winner codes of only `band_rows` rows (a multiple of 64; 0 = chosen so that
- * they take about 8 GB) exist at any time.  Pass 1 fills score-only and keeps the hand-off row in
- * front of every band (8 bytes per column and band); pass 2 goes through the bands bottom-up,
+ * psa_align, but the winner codes of only `band_rows` rows (rounded up to a multiple of 256; 0 = chosen so that
+ * they take about 8 GB) exist at any time.  Pass 1 fills score-only (one launch) and keeps the row
+ * in front of every band (8 bytes per column and band); pass 2 goes through the bands bottom-up,
  * refills one band with codes -- only the columns left of where the walk enters it -- and walks it.
  * About twice the work of psa_align, for pairs whose codes (0.75 byte per cell) do not fit in HBM.
  * psa_align switches to it by itself when they do not, or when PSA_BAND_ROWS is set. */

@@ -541,6 +541,8 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     c.gin = p.ring + (size_t)(((sg - 1) / kNW) & 1) * p.Wpad;  // bottom row of strip sg-1
     c.gout = p.ring + (size_t)((sg / kNW) & 1) * p.Wpad;
     c.gdump = p.ring + 2 * (size_t)p.Wpad + lane;
+    if (const u64* ci = ckpt_row_in(p, sg)) c.gin = ci;       // banded mode: band boundaries go through
+    if (u64* co = ckpt_row_out(p, sg)) c.gout = co;           // the checkpoint rows, not the ring
     c.carryD = D_up;          // D of column t0-1 of the row above (wave 0 path)
     for (int j = 0; j < kGDist; ++j) c.gq[j] = 0;
     c.gq_valid = 0;

@@ -63,8 +63,9 @@ int64_t band_rows_for(int64_t n, int Q) {
     int64_t want = g_band_rows_request;
     if (want <= 0) if (const char* e = getenv("PSA_BAND_ROWS")) want = atoll(e);
     if (want <= 0) want = 64 * std::max<int64_t>(1, (8LL << 30) / ((int64_t)Q * 3072));
-    want = std::max<int64_t>(64, (want / 64) * 64);
-    return std::min<int64_t>(want, ((n + 63) / 64) * 64);
+    const int64_t wg_rows = 64 * psa::kNW;   // band boundaries coincide with workgroup boundaries
+    want = std::max<int64_t>(wg_rows, ((want + wg_rows - 1) / wg_rows) * wg_rows);
+    return std::min<int64_t>(want, ((n + wg_rows - 1) / wg_rows) * wg_rows);
 }
 
 }  // namespace
@@ -209,7 +210,7 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
             s->band_rows = band_rows_for(n, s->Q);
             code_strips = s->band_rows / 64;
             const int64_t nbands = (n + s->band_rows - 1) / s->band_rows;
-            CREATE_TRY(hipMalloc(&s->ckpt, sizeof(psa::u64) * (size_t)nbands * (2 * (size_t)s->Wpad + 64)));
+            CREATE_TRY(hipMalloc(&s->ckpt, sizeof(psa::u64) * (size_t)(nbands + 1) * (size_t)s->Wpad));
         }
         s->code_bytes = (size_t)code_strips * (size_t)s->Q * 3 * 64 * 4 * sizeof(uint32_t);
         CREATE_TRY(hipMalloc(&s->codes, s->code_bytes));
@@ -259,9 +260,13 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
     if ((s->c0 == 0) != (left_dev == nullptr))
         return fail(PSA_E_ARG, "psa_stripe_fill_rows: left boundary must be given exactly when c0 > 0");
     hipStream_t st = (hipStream_t)stream;
-    if (r0 == 0) {
+    if (r0 == 0 || o.any_order) {
+        // A launch that does not continue the previous one must not find that one's granules: a granule
+        // is recognised by its tag (strip number), and a strip that finds a left-over with the right tag
+        // runs ahead of the strips it should follow and overwrites ring slots they have not read yet.
+        // (A banded refill takes its input from the checkpoint row, never from the ring.)
         HIP_TRY(hipMemsetAsync(s->ring, 0, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64), st));
-        s->corner_cur = 0;
+        if (r0 == 0) s->corner_cur = 0;
     }
     HIP_TRY(hipMemsetAsync(s->ctrl, 0, kCtrlBytes, st));
     psa::FillArgs fa;
@@ -278,6 +283,7 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
     fa.ticket = s->ctrl;
     fa.abort_flag = s->ctrl + 1;
     fa.prof = nullptr;
+    fa.ckpt = s->ckpt; fa.band_strips = s->band_rows / 64;
     const char* prof_path = getenv("PSA_PROFILE_STRIPS");
     psa::u64* prof_dev = nullptr;
     const unsigned nstrips_prof = (unsigned)((r1 - r0 + 63) / 64);
@@ -595,16 +601,14 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
     StripeSet owner;
     owner.st.push_back(s);
     const int64_t B = s->band_rows;
-    const int64_t nbands = (n + B - 1) / B;
-    const size_t ring_words = 2 * (size_t)s->Wpad + 64;
-    // pass 1: score only; the hand-off ring as it stands before every band is kept
-    for (int64_t bnd = 0; bnd < nbands; ++bnd) {
-        const int64_t r0 = bnd * B, r1 = std::min(n, r0 + B);
-        if (bnd) HIP_TRY(hipMemcpyAsync(s->ckpt + (size_t)bnd * ring_words, s->ring, sizeof(psa::u64) * ring_words,
-                                        hipMemcpyDeviceToDevice, nullptr));
+    // pass 1: score only, one launch; the last strip of every band leaves its bottom row in ckpt
+    {
+        // (granules are recognised by their tag = strip number: rows left over from another pair must go)
+        const int64_t nbands = (n + B - 1) / B;
+        HIP_TRY(hipMemsetAsync(s->ckpt, 0, sizeof(psa::u64) * (size_t)(nbands + 1) * (size_t)s->Wpad, nullptr));
         FillOpts fo;
         fo.codes = 0;
-        if ((rc = fill_rows_impl(s, r0, r1, nullptr, nullptr, nullptr, fo))) return rc;
+        if ((rc = fill_rows_impl(s, 0, n, nullptr, nullptr, nullptr, fo))) return rc;
     }
     int32_t t[3];
     if ((rc = psa_stripe_final(s, nullptr, t))) return rc;
@@ -623,10 +627,7 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
         const int Qr = (Wr + 63 + 63) / 64;
         uint32_t* base = (uint32_t*)((uintptr_t)s->codes -
                                      sizeof(uint32_t) * (uintptr_t)psa::code_word_index(r0 / 64, Qr, 0, 0, 0, 0));
-        if (bnd) rc = hipMemcpyAsync(s->ring, s->ckpt + (size_t)bnd * ring_words, sizeof(psa::u64) * ring_words,
-                                     hipMemcpyDeviceToDevice, nullptr) == hipSuccess ? PSA_OK
-                                                                                       : fail(PSA_E_HIP, "restoring a band's hand-off row failed");
-        if (rc) break;
+        if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "banded: band %lld rows %lld..%lld columns %d, walk at (%lld,%lld,%d)\n", (long long)bnd, (long long)r0, (long long)r1, Wr, (long long)i, (long long)j, k);
         FillOpts fo;
         fo.codes = 1; fo.W = Wr; fo.codes_base = base; fo.any_order = true;
         if ((rc = fill_rows_impl(s, r0, r1, nullptr, nullptr, nullptr, fo))) break;

@@ -32,7 +32,18 @@ struct FillArgs {
     unsigned* ticket;        // strip ticket counter (zeroed per launch)
     unsigned* abort_flag;    // set when a bounded spin expires
     u64* prof;               // optional [strips][4]: start, end (100 MHz ticks), placement; null = off
+    u64* ckpt;               // banded mode: [bands][Wpad] granules; the last strip of band b-1 publishes its
+    int64_t band_strips;     // bottom row to ckpt[b] instead of the ring and band b's first strip reads it
+                             // there (0 = off).  A multiple of the strips per workgroup.
 };
+
+// where strip sg's bottom row goes / where strip sg's input row comes from, when it is not the ring
+__device__ __forceinline__ u64* ckpt_row_out(const FillArgs& p, int64_t sg) {
+    return (p.band_strips > 0 && (sg + 1) % p.band_strips == 0) ? p.ckpt + (size_t)((sg + 1) / p.band_strips) * p.Wpad : nullptr;
+}
+__device__ __forceinline__ const u64* ckpt_row_in(const FillArgs& p, int64_t sg) {
+    return (p.band_strips > 0 && sg > 0 && sg % p.band_strips == 0) ? p.ckpt + (size_t)(sg / p.band_strips) * p.Wpad : nullptr;
+}
 
 __device__ __forceinline__ u64 load_granule(const u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -87,6 +98,8 @@ __global__ __launch_bounds__(64) void fill_strips_v1(FillArgs p) {
     int topD = 0, topV = 0, bch = 0;
     const u64* ring_in = p.ring + (size_t)((sg + 1) & 1) * p.Wpad;  // parity of strip sg-1
     u64* ring_out = p.ring + (size_t)(sg & 1) * p.Wpad;
+    if (const u64* ci = ckpt_row_in(p, sg)) ring_in = ci;
+    if (u64* co = ckpt_row_out(p, sg)) ring_out = co;
     const u64 tag_in = (u64)sg, tag_out = (u64)(sg + 1);
 
     for (int q = 0; q < p.Q; ++q) {

@@ -196,7 +196,7 @@ def test_traceback_kernels_agree(monkeypatch):
         assert r.score == sc and np.array_equal(r.ai, ai) and np.array_equal(r.bj, bj)
 
 
-@pytest.mark.parametrize("band", [64, 128, 320])
+@pytest.mark.parametrize("band", [256, 512, 768])
 def test_banded_linear_space_alignment(band):
     """psa_align_banded (codes of one band of rows at a time) against the oracle: sizes that
     are no multiple of the band, alphabets with long runs and long gaps, a pair shorter than a band."""
