@@ -238,9 +238,6 @@ struct StripCtx {
     unsigned gq_valid;      // (u) bit j: gq[j] holds a request
     unsigned qd[8], hv[4];  // winner-bit words of the current superblock (see run_superblock)
     unsigned wait_in, wait_room;  // (u) spin iterations, for the profile only
-#ifdef PSA_EXP_TIMING
-    unsigned tsec[4];
-#endif
 };
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -402,9 +399,6 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
 template <bool CODES, int MODE, int IN, int OUT>
 __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, const int sb) {
     const int t0 = sb * 64;
-#ifdef PSA_EXP_MID
-    if (p.prof && c.lane == 0 && sb == p.Q / 2) p.prof[4 * ((c.sg << 6) - p.r0 >> 6) + 2] = wall_clock64();
-#endif
     // table words one superblock ahead (8 new words; word 8 of the current set is word 0 of the next)
     const u32x4_a4 n0 = *(const u32x4_a4*)(c.trow + c.mword_idx + 9);
     const u32x4_a4 n1 = *(const u32x4_a4*)(c.trow + c.mword_idx + 13);
@@ -547,9 +541,6 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     for (int j = 0; j < kGDist; ++j) c.gq[j] = 0;
     c.gq_valid = 0;
     c.wait_in = c.wait_room = 0;
-#ifdef PSA_EXP_TIMING
-    c.tsec[0] = c.tsec[1] = c.tsec[2] = c.tsec[3] = 0;
-#endif
 
     const int nblocks = c.nblocks = p.Q * (64 / kBlk);
     // A workgroup far down the chain waits for a long time before its first granule arrives.
@@ -586,9 +577,6 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
         p.prof[4 * s + 0] = wall_clock64();
         p.prof[4 * s + 2] = ((u64)xcc << 32) | hwid;
     }
-#ifdef PSA_EXP_TIMING
-    const unsigned long long tc0 = __builtin_readcyclecounter();
-#endif
 
     // Wide stripes: head + steady state compiled per role, then a tail that captures the right
     // boundary.  Narrow stripes (W < 128): one generic, fully predicated loop.
@@ -624,12 +612,7 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
 
     if (p.prof && lane == 0) {
         p.prof[4 * s + 1] = wall_clock64();
-#ifdef PSA_EXP_TIMING
-        p.prof[4 * s + 2] = ((u64)c.tsec[0] << 32) | c.tsec[1];
-        p.prof[4 * s + 3] = ((u64)c.tsec[2] << 32) | c.tsec[3];
-#else
         p.prof[4 * s + 3] = ((u64)c.wait_room << 32) | c.wait_in;
-#endif
     }
     // ---- trailing granule group (columns whose flush block lies beyond the last block) ----
     if (c.to_hbm) {

@@ -289,7 +289,6 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
     const unsigned nstrips_prof = (unsigned)((r1 - r0 + 63) / 64);
     if (prof_path && s->use_v2) {
         size_t prof_words = 4 * (size_t)nstrips_prof;
-        if (getenv("PSA_PROFILE_HANDOFF")) prof_words += 4 * (size_t)(nstrips_prof + 1) * (size_t)(s->Q * 4);
         HIP_TRY(hipMalloc(&prof_dev, sizeof(psa::u64) * prof_words));
         HIP_TRY(hipMemsetAsync(prof_dev, 0, sizeof(psa::u64) * prof_words, st));
         fa.prof = prof_dev;
@@ -317,20 +316,6 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
                         (long long)(h[4 * k + 1] - h[0]), h[4 * k + 2] >> 32, h[4 * k + 2] & 0xffffffffu,
                         h[4 * k + 3] & 0xffffffffu, h[4 * k + 3] >> 32);
             fclose(f);
-        }
-        if (const char* hp = getenv("PSA_PROFILE_HANDOFF")) {
-            const size_t nb = (size_t)s->Q * 4;
-            std::vector<psa::u64> g(4 * nb);
-            const unsigned strip = (unsigned)atoi(hp);
-            HIP_TRY(hipMemcpy(g.data(), prof_dev + 4 * (size_t)nstrips_prof + (size_t)strip * nb * 4,
-                              sizeof(psa::u64) * g.size(), hipMemcpyDeviceToHost));
-            if (FILE* f = fopen("gpurun_out/handoff.csv", "w")) {
-                fprintf(f, "blk,look,got,pre_ok,spins,published\n");
-                for (size_t b = 0; b < nb; ++b)
-                    fprintf(f, "%zu,%lld,%lld,%llu,%llu,%lld\n", b, (long long)(g[4 * b] - h[0]), (long long)(g[4 * b + 1] - h[0]),
-                            g[4 * b + 2] >> 32, g[4 * b + 2] & 0xffffffffu, (long long)(g[4 * b + 3] - h[0]));
-                fclose(f);
-            }
         }
         hipFree(prof_dev);
         prof_dev = nullptr;

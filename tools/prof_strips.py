@@ -22,13 +22,6 @@ print("start lag us: med %.2f mean %.2f ; by wave-in-wg:" % (np.median(lag), lag
 endlag = np.diff(end)
 print("end lag us: med %.2f mean %.2f ; by wave-in-wg:" % (np.median(endlag), endlag.mean()),
       [round(float(np.median(endlag[w::4])), 2) for w in range(4)])
-mid = (d[:,4] + d[:,3]*4294967296.0 - 0) 
-if os.environ.get("PSA_MID"):
-    # prof[2] holds an absolute mid-sweep tick; make it relative using strip 0
-    m = mid - mid[0]
-    ml = np.diff(m) / 100.0
-    print("mid-sweep lag us: med %.2f mean %.2f by wave %s" % (np.median(ml), ml.mean(), [round(float(np.median(ml[w::4])),2) for w in range(4)]))
-    print("mid lags first 12:", [round(float(x),2) for x in ml[:12]])
 hw = d[:, 4].astype(np.int64); xcc = d[:, 3].astype(np.int64)
 cu = (hw >> 8) & 0xf; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
 key = xcc * 1000 + se * 100 + cu
