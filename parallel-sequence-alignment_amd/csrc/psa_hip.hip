@@ -607,7 +607,7 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
     // pass 2: bottom band first; refill with codes the columns the walk can still reach, walk, hand on
     for (int64_t bnd = (i - 1) / B; bnd >= 0 && i > 0 && j > 0 && rc == PSA_OK; --bnd) {
         const int64_t r0 = bnd * B, r1 = std::min(n, r0 + B);
-        if (i - (k != 2) <= r0) continue;                      // the walk left this band without a step in it
+        if (r0 > 0 && i - (k != 2) <= r0) continue;            // the walk left this band without a step in it
         const int Wr = (int)std::min<int64_t>(s->W, j);
         const int Qr = (Wr + 63 + 63) / 64;
         uint32_t* base = (uint32_t*)((uintptr_t)s->codes -

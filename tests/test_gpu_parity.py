@@ -225,3 +225,14 @@ def test_banded_through_env_and_large(monkeypatch):
     assert plain.score == banded.score and np.array_equal(plain.ai, banded.ai) and np.array_equal(plain.bj, banded.bj)
     sc, ai, bj = O.align(a, b)
     assert banded.score == sc and np.array_equal(banded.ai, ai) and np.array_equal(banded.bj, bj)
+
+
+def test_banded_generic_kernels_and_tiny():
+    """Banded mode with the generic kernels (more than 32 symbols -> fill_strips_v1) and degenerate sizes."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(40, 100, 777).astype(np.uint8)      # 60 symbols
+    b = rng.integers(40, 100, 555).astype(np.uint8)
+    for x, y in ((a, b), (a[:1], b), (a, b[:1]), (a[:300], a[:300])):
+        res = psa_amd.align(x, y, 1, band_rows=256)
+        sc, ai, bj = O.align(x, y)
+        assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (x.size, y.size)
