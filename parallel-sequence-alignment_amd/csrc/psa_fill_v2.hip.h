@@ -39,7 +39,8 @@ constexpr int kTabPad = 16;    // table words (8 columns each) of padding in fro
 struct FillArgs2 {
     FillArgs base;
     const uint8_t* a_ids;     // symbol id (< kMaxSym) of every row of A
-    const uint32_t* eqtab;    // [kMaxSym][tab_pitch] words, nibble c%8 of word kTabPad + c/8 = score(sym, B[c])
+    const uint32_t* eqtab;    // [kMaxSym][tab_pitch] words, byte c%4 of word kTabPad + c/4 = score(sym, B[c]): a byte, so that
+                              // the step adds it with an SDWA byte select and needs no extract
     int tab_pitch;
 };
 
@@ -70,14 +71,14 @@ __global__ void build_eqtab(const uint8_t* b, int W, const unsigned* meta, const
     const int w = blockIdx.x * blockDim.x + threadIdx.x;  // word index inside the row
     const unsigned sym = blockIdx.y;
     if (w >= pitch) return;
-    uint32_t word = 0x66666666u;
+    uint32_t word = 0x06060606u;
     if (sym < meta[0] && sym < (unsigned)kMaxSym) {
-        const int c0 = (w - kTabPad) * 8;
+        const int c0 = (w - kTabPad) * 4;
         const unsigned ch = inv[sym];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 4; ++k) {
             const int c = c0 + k;
-            if (c >= 0 && c < W && b[c] == ch) word += 2u << (4 * k);
+            if (c >= 0 && c < W && b[c] == ch) word += 2u << (8 * k);
         }
     }
     tab[(size_t)sym * pitch + w] = word;
@@ -137,14 +138,25 @@ enum : int { kFast = 0, kHead = 1, kTail = 2, kGeneric = 3 };
 
 // One anti-diagonal step.  k = step inside the block (compile-time), pre = lane 0's inputs for
 // steps 2j, 2j+1 as (D of column-1, V of column) pairs, pa/pb = where this lane drops (D, V).
+// a + byte `sel` of w in one instruction (SDWA source select): the substitution score needs no extract
+__device__ __forceinline__ int add_byte(int a, unsigned w, int sel) {
+    int r;
+    switch (sel) {
+        case 0: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(w)); break;
+        case 1: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(w)); break;
+        case 2: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(w)); break;
+        default: asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(w)); break;
+    }
+    return r;
+}
+
 template <bool CODES, int MODE>
 __device__ __forceinline__ void step16(const int k, StripState& S, const int4& pre, const unsigned mword,
                                        int* pa, int* pb, const int t, const int lane, const int W,
                                        const bool row_ok) {
-    const int f = (int)__builtin_amdgcn_ubfe(mword, 4 * (k & 7), 4);
     const int preD = (k & 1) ? pre.z : pre.x;
     const int preV = (k & 1) ? pre.w : pre.y;
-    const int x1 = shift_down1(preD, (k & 1) ? S.D1 : S.D0) + f;
+    const int x1 = add_byte(shift_down1(preD, (k & 1) ? S.D1 : S.D0), mword, k & 3);
     const int x3 = shift_down1(preV, S.V);
     const int x2 = S.H;
     const int x2p = x2 + 2, x3p = x3 + 2;
@@ -221,7 +233,7 @@ struct StripCtx {
     // substitution table window
     const uint32_t* trow;
     int msh, mword_idx;
-    unsigned mw[9];         // table words covering this superblock's 64 columns (+ alignment spill)
+    unsigned mw[17];        // table words covering this superblock's 64 columns (+ alignment spill)
     int prod_seen;          // (u) last value read from the producer's counter
     // hand-off
     int2* my_ring;
@@ -251,7 +263,7 @@ enum : int { kAny = -1, kInLds = 0, kInHbm = 1, kInTop = 2, kOutLds = 0, kOutHbm
 // One block of 16 steps: wait for lane 0's inputs, load them, run the steps, post progress.
 template <bool CODES, int MODE, int IN, int OUT, int JB>
 __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, const int t0,
-                                          const unsigned mlo, const unsigned mhi) {
+                                          const unsigned (&mq)[4]) {
     const int lane = c.lane;
     const int W = c.W;
     const bool from_lds = (IN == kAny) ? c.from_lds : (IN == kInLds);
@@ -366,7 +378,7 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     // ---- 2. the sixteen steps ----
 #pragma unroll
     for (int k = 0; k < kFlushAt; ++k)
-        step16<CODES, MODE>(k, c.S, pre[k >> 1], (k < 8) ? mlo : mhi, pa, pb, t0 + k, lane, W, c.row_ok);
+        step16<CODES, MODE>(k, c.S, pre[k >> 1], mq[k >> 2], pa, pb, t0 + k, lane, W, c.row_ok);
     if (OUT == kAny || OUT == kOutHbm) {
         const u64 gran = (c.tag_out << 32) | ((unsigned)fd << 2) | (unsigned)(fv - fd);
         if (flush_always) {
@@ -383,7 +395,7 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     }
 #pragma unroll
     for (int k = kFlushAt; k < kBlk; ++k) {
-        step16<CODES, MODE>(k, c.S, pre[k >> 1], (k < 8) ? mlo : mhi, pa, pb, t0 + k, lane, W, c.row_ok);
+        step16<CODES, MODE>(k, c.S, pre[k >> 1], mq[k >> 2], pa, pb, t0 + k, lane, W, c.row_ok);
         if (CODES && (k & 7) == 7) c.qd[2 * JB + (k >> 3)] = c.S.aQ;   // eight 4-bit steps fill a word
     }
 
@@ -399,9 +411,11 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
 template <bool CODES, int MODE, int IN, int OUT>
 __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, const int sb) {
     const int t0 = sb * 64;
-    // table words one superblock ahead (8 new words; word 8 of the current set is word 0 of the next)
-    const u32x4_a4 n0 = *(const u32x4_a4*)(c.trow + c.mword_idx + 9);
-    const u32x4_a4 n1 = *(const u32x4_a4*)(c.trow + c.mword_idx + 13);
+    // table words one superblock ahead (16 new words; word 16 of the current set is word 0 of the next)
+    const u32x4_a4 n0 = *(const u32x4_a4*)(c.trow + c.mword_idx + 17);
+    const u32x4_a4 n1 = *(const u32x4_a4*)(c.trow + c.mword_idx + 21);
+    const u32x4_a4 n2 = *(const u32x4_a4*)(c.trow + c.mword_idx + 25);
+    const u32x4_a4 n3 = *(const u32x4_a4*)(c.trow + c.mword_idx + 29);
     // room in the consumer's ring for the slots this superblock writes (up to t0 + 65)
     if ((OUT == kAny) ? c.to_lds : (OUT == kOutLds)) {
         Spin spins;
@@ -412,9 +426,11 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
     }
 #define PSA_BLOCK(j)                                                                                   \
     {                                                                                                  \
-        const unsigned mlo = __builtin_amdgcn_alignbit(c.mw[2 * j + 1], c.mw[2 * j], c.msh);           \
-        const unsigned mhi = __builtin_amdgcn_alignbit(c.mw[2 * j + 2], c.mw[2 * j + 1], c.msh);       \
-        if (!run_block<CODES, MODE, IN, OUT, j>(c, lds, p, t0 + j * kBlk, mlo, mhi)) return false;     \
+        const unsigned mq[4] = {__builtin_amdgcn_alignbit(c.mw[4 * j + 1], c.mw[4 * j], c.msh),        \
+                                __builtin_amdgcn_alignbit(c.mw[4 * j + 2], c.mw[4 * j + 1], c.msh),    \
+                                __builtin_amdgcn_alignbit(c.mw[4 * j + 3], c.mw[4 * j + 2], c.msh),    \
+                                __builtin_amdgcn_alignbit(c.mw[4 * j + 4], c.mw[4 * j + 3], c.msh)};   \
+        if (!run_block<CODES, MODE, IN, OUT, j>(c, lds, p, t0 + j * kBlk, mq)) return false;           \
     }
     PSA_BLOCK(0)
     PSA_BLOCK(1)
@@ -429,10 +445,12 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
         dst[64] = make_uint4(c.qd[4], c.qd[5], c.qd[6], c.qd[7]);
         dst[128] = make_uint4(c.hv[0], c.hv[1], c.hv[2], c.hv[3]);
     }
-    c.mw[0] = c.mw[8];
+    c.mw[0] = c.mw[16];
     c.mw[1] = n0.x; c.mw[2] = n0.y; c.mw[3] = n0.z; c.mw[4] = n0.w;
     c.mw[5] = n1.x; c.mw[6] = n1.y; c.mw[7] = n1.z; c.mw[8] = n1.w;
-    c.mword_idx += 8;
+    c.mw[9] = n2.x; c.mw[10] = n2.y; c.mw[11] = n2.z; c.mw[12] = n2.w;
+    c.mw[13] = n3.x; c.mw[14] = n3.y; c.mw[15] = n3.z; c.mw[16] = n3.w;
+    c.mword_idx += 16;
     return true;
 }
 
@@ -517,10 +535,10 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     // ---- substitution table row of this lane; window of 16 columns starting at t0 - lane ----
     const int sym = row_ok ? (int)q.a_ids[i - 1] : 0;
     c.trow = q.eqtab + (size_t)sym * q.tab_pitch + kTabPad;
-    c.msh = 4 * ((64 - lane) & 7);                      // (t0 - lane) mod 8 nibbles, t0 % 16 == 0
-    c.mword_idx = (-lane - ((64 - lane) & 7)) / 8;      // floor((0 - lane) / 8), exact division
+    c.msh = 8 * ((64 - lane) & 3);                      // (t0 - lane) mod 4 bytes, t0 % 16 == 0
+    c.mword_idx = (-lane - ((64 - lane) & 3)) / 4;      // floor((0 - lane) / 4), exact division
 #pragma unroll
-    for (int j = 0; j < 9; ++j) c.mw[j] = c.trow[c.mword_idx + j];
+    for (int j = 0; j < 17; ++j) c.mw[j] = c.trow[c.mword_idx + j];
     c.prod_seen = 0;
 
     // ---- hand-off plumbing ----

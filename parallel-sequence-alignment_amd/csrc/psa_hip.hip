@@ -220,7 +220,7 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
         CREATE_TRY(hipMalloc(&s->tb_state, sizeof(int64_t) * 12));
     }
     for (auto& e : s->ev) CREATE_TRY(hipEventCreate(&e));
-    s->tab_pitch = psa::kTabPad + (64 * s->Q + 64) / 8 + 8;
+    s->tab_pitch = psa::kTabPad + (64 * s->Q + 64) / 4 + 40;   // a byte per column; the last superblock requests 32 words ahead
     CREATE_TRY(hipMalloc(&s->a_ids, (size_t)n));
     CREATE_TRY(hipMalloc(&s->alpha, kAlphaBytes));
     CREATE_TRY(hipMalloc(&s->eqtab, sizeof(uint32_t) * (size_t)psa::kMaxSym * (size_t)s->tab_pitch));
