@@ -13,7 +13,7 @@ column stripes, boundary columns streamed g -> g+1 with RCCL send/recv (bench_mu
 dependency chain is n + m steps long on any number of GPUs, so it buys capacity, not time, at
 2^16).  One pair alone cannot fill the GPU (its anti-diagonal
 dependency chain is n + m steps long whatever the hardware), so the job keeps --in-flight
-(default 4) independent alignments going at a time, each on its own stream with its own code
+(default 6) independent alignments going at a time, each on its own stream with its own code
 buffer; "value" is the job's throughput, "one_pair_alone" the latency of a single alignment, and
 the roofline object is the fill kernel measured alone.  Rank 0 prints ONE JSON line.
 
@@ -29,8 +29,9 @@ import time
 
 # Every alignment in flight has a stream of its own; with HIP's default of 4 hardware queues per process
 # streams share queues, and one stream's small kernels wait behind another stream's fill.
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8:
-    os.environ["GPU_MAX_HW_QUEUES"] = "8"
+_HWQ = min(32, int(os.environ.get("PSA_BENCH_HW_QUEUES", "8")))
+if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < _HWQ:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(_HWQ)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -45,11 +46,12 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1)")
-    ap.add_argument("--in-flight", type=int, default=4, help="independent alignments in flight (N = 1)")
+    ap.add_argument("--in-flight", type=int, default=6,
+                    help="independent alignments in flight per GPU (at most 8: one hardware queue each)")
     ap.add_argument("--mode", choices=["pairs", "stripes"], default="pairs",
                     help="N > 1: independent pairs per GPU (default) or one pair in N column stripes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,7 +144,9 @@ def single_gpu(args):
     b = psa_amd.synth_protein(0xB0000000 + k, m)
     a_dev = torch.from_numpy(a).cuda()
     b_dev = torch.from_numpy(b).cuda()
-    P = max(1, args.in_flight)
+    # more streams than hardware queues makes the GPU's scheduler time-slice the queues, and a fill that
+    # is switched out with its 96 KB of LDS per workgroup takes seconds (measured: 10 in flight = 1 s each)
+    P = min(8, max(1, args.in_flight))
     stripes = [psa_amd.Stripe(a, b, 0, m, traceback=True) for _ in range(P)]
     streams = [torch.cuda.Stream() for _ in range(P)]
     cap = 2 * (n + m) + 2
