@@ -58,7 +58,7 @@ int pick3(const int32_t t[3], int32_t* v) {
 constexpr size_t kCtrlBytes = 256;
 
 // rows per band in banded mode: PSA_BAND_ROWS, else as many strips as 8 GiB of codes hold
-int64_t g_band_rows_request = 0;   // set by psa_align_banded around the stripe's creation
+thread_local int64_t g_band_rows_request = 0;   // set by psa_align_banded around the stripe's creation
 int64_t band_rows_for(int64_t n, int Q) {
     int64_t want = g_band_rows_request;
     if (want <= 0) if (const char* e = getenv("PSA_BAND_ROWS")) want = atoll(e);
@@ -778,7 +778,7 @@ int psa_read_fasta_records(const char* path, uint8_t** seqs_out, int64_t** offse
     fclose(f);
     uint8_t* buf = (uint8_t*)malloc(seq.size() + 1);
     int64_t* off = (int64_t*)malloc(sizeof(int64_t) * (starts.size() + 1));
-    if (!buf || !off) { free(buf); free(off); return fail(PSA_E_ARG, "psa_read_fasta_records: out of memory"); }
+    if (!buf || !off) { free(buf); free(off); return fail(PSA_E_NOMEM, "psa_read_fasta_records: out of memory"); }
     memcpy(buf, seq.data(), seq.size());
     for (size_t r = 0; r < starts.size(); ++r) off[r] = starts[r];
     off[starts.size()] = (int64_t)seq.size();

@@ -106,6 +106,23 @@ def test_large_score_only_property():
     assert psa_amd.score(a, b, 4) == want
 
 
+def test_full_size_pair_vs_oracle():
+    # BASELINE config 4 at the size the metric is quoted on (2^16 x 2^16, 4.3 G cells): complete alignment,
+    # every column equal to the oracle's (threads of the oracle: its striped variant, a few seconds)
+    k = 16
+    a = psa_amd.synth_protein(0xA0000000 + k, 1 << k)
+    b = psa_amd.synth_protein(0xB0000000 + k, 1 << k)
+    sc, ai, bj = O.align(a, b, min(16, os.cpu_count() or 1))
+    res = psa_amd.align(a, b, 1)
+    assert res.score == sc == 12738
+    assert np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj)
+    # size-independent properties: indices never go back, no column is gap/gap (the reference's prefix
+    # fix-up, simple.cpp:279-290, may repeat the first aligned residue, so "each residue once" does not hold)
+    for x in (res.ai, res.bj):
+        assert np.all(np.diff(x[x >= 0]) >= 0) and x[x >= 0][-1] == (1 << k) - 1
+    assert not np.any((res.ai < 0) & (res.bj < 0))
+
+
 def test_cli_byte_exact(golden_dir):
     exe = os.path.join(ROOT, "simple")
     assert os.path.exists(exe), "run `make` first"
