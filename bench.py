@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1)")

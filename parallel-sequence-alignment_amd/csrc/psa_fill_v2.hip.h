@@ -28,7 +28,10 @@ namespace psa {
 #define PSA_GDIST 2
 #endif
 constexpr int kGDist = PSA_GDIST;  // granule requests run this many blocks ahead (1, 2 or 4)
-constexpr int kKeepoutWords = 24 * 1024;   // 96 KB of LDS kept out of use, see fill_strips_v2
+#ifndef PSA_KEEPOUT_WORDS
+#define PSA_KEEPOUT_WORDS (24 * 1024)
+#endif
+constexpr int kKeepoutWords = PSA_KEEPOUT_WORDS;   // 96 KB of LDS kept out of use, see fill_strips_v2
 constexpr int kFrontWord = 32;  // control block: [0] ticket, [1] abort flag, [32] front (own cache line)
 constexpr int kNW = 4;         // strips (wavefronts) per workgroup
 constexpr int kRing = 256;     // LDS ring slots per strip boundary (8 bytes each)

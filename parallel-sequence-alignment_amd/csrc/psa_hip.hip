@@ -309,7 +309,14 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
     if (prof_dev) {  // diagnostic only: dump per-strip start/end ticks and placement
         std::vector<psa::u64> h(4 * (size_t)nstrips_prof);
         HIP_TRY(hipMemcpy(h.data(), prof_dev, sizeof(psa::u64) * h.size(), hipMemcpyDeviceToHost));
-        if (FILE* f = fopen(prof_path, "w")) {
+        std::string pp = prof_path;
+        if (!pp.empty() && pp.back() == '+') {   // one file per stripe object
+            char suffix[32];
+            snprintf(suffix, sizeof suffix, "%p", (void*)s);
+            pp.pop_back();
+            pp += suffix;
+        }
+        if (FILE* f = fopen(pp.c_str(), "w")) {
             fprintf(f, "strip,start,end,xcc,hwid,wait_in,wait_room\n");
             for (unsigned k = 0; k < nstrips_prof; ++k)
                 fprintf(f, "%u,%lld,%lld,%llu,%llu,%llu,%llu\n", k, (long long)(h[4 * k] - h[0]),
