@@ -308,6 +308,7 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
     s->fill_timed = true;
     if (prof_dev) {  // diagnostic only: dump per-strip start/end ticks and placement
         std::vector<psa::u64> h(4 * (size_t)nstrips_prof);
+        HIP_TRY(hipStreamSynchronize(st));   // (a stream created non-blocking is not ordered against the copy below)
         HIP_TRY(hipMemcpy(h.data(), prof_dev, sizeof(psa::u64) * h.size(), hipMemcpyDeviceToHost));
         std::string pp = prof_path;
         if (!pp.empty() && pp.back() == '+') {   // one file per stripe object

@@ -13,10 +13,13 @@ stripes = [psa_amd.Stripe(a, b, 0, m, traceback=codes) for _ in range(T)]
 streams = [torch.cuda.Stream() for _ in range(T)]
 os.makedirs("gpurun_out/loaded", exist_ok=True)
 for f in glob.glob("gpurun_out/loaded/s*"): os.remove(f)
+PROFILE_AT = -1
 def worker(i, reps):
     s = streams[i].cuda_stream
-    for _ in range(reps):
+    for r in range(reps):
+        if i == 0 and r == PROFILE_AT: os.environ["PSA_PROFILE_STRIPS"] = "gpurun_out/loaded/s+"
         stripes[i].fill_rows(0, n, None, None, s)
+        if i == 0 and r == PROFILE_AT: os.environ.pop("PSA_PROFILE_STRIPS", None)
     stripes[i].final(s)
 def run(reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -26,9 +29,9 @@ def run(reps):
 run(2)
 dt = run(6)
 print("unprofiled: %.2f ms per fill, %.0f GCUPS" % (dt * 1e3 / (6 * T), 6 * T * float(n) * m / dt / 1e9))
-os.environ["PSA_PROFILE_STRIPS"] = "gpurun_out/loaded/s+"
-dt = run(6)
-print("profiled: %.2f ms per fill" % (dt * 1e3 / (6 * T)))
+PROFILE_AT = 5
+dt = run(10)
+print("profiled: %.2f ms per fill" % (dt * 1e3 / (10 * T)))
 for f in sorted(glob.glob("gpurun_out/loaded/s*")):
     d = np.loadtxt(f, delimiter=",", skiprows=1)
     start, end = d[:, 1] / 100.0, d[:, 2] / 100.0
