@@ -27,6 +27,14 @@ namespace psa {
 #ifndef PSA_GDIST
 #define PSA_GDIST 2
 #endif
+#ifndef PSA_GRAN_COLS
+#define PSA_GRAN_COLS 32
+#endif
+// Columns of the row above that wave 0 of a workgroup takes over from HBM at a time in the steady
+// state: 16 (every block, as head and tail do), 32 or 64.  Fetch, tag check, unpack, lane shift and
+// the write into the wave's own ring cost ~27 instructions a time; per block that made the
+// HBM-fed strip 8 % slower than the LDS-fed ones, and the slowest strip sets the pace of its chain.
+constexpr int kGranCols = PSA_GRAN_COLS;
 constexpr int kGDist = PSA_GDIST;  // granule requests run this many blocks ahead (1, 2 or 4)
 #ifndef PSA_KEEPOUT_WORDS
 #define PSA_KEEPOUT_WORDS (24 * 1024)
@@ -249,6 +257,7 @@ struct StripCtx {
     u64* gdump;             // 64 granules behind the ring that nobody reads (one per lane)
     u64 tag_in, tag_out;
     int carryD;
+    u64 gbatch;             // steady state, kGranCols > 16: the next kGranCols granules, one per lane
     u64 gq[kGDist];         // granules requested kGDist blocks ahead (wave 0 path), by block index mod kGDist
     unsigned gq_valid;      // (u) bit j: gq[j] holds a request
     unsigned qd[8], hv[4];  // winner-bit words of the current superblock (see run_superblock)
@@ -285,6 +294,28 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
                 }
                 c.wait_in += spins.n;
             }
+        }
+    } else if (MODE == kFast && IN == kInHbm && kGranCols > kBlk) {
+        // steady state, wave 0: kGranCols columns at a time, every lane one column (columns past the end
+        // are clamped to the last one: a real granule, whose values nobody uses).  Requested one batch
+        // ago; all loads unconditional, so the waits on the vector-memory counter stay counted ones.
+        if (JB % (kGranCols / kBlk) == 0) {
+            const int lcol = lane & (kGranCols - 1);
+            u64 g = c.gbatch;
+            if (!__all((g >> 32) == c.tag_in)) {
+                Spin spins;
+                do {
+                    if (spin_expired(spins, p.abort_flag)) return false;
+                    g = load_granule(c.gin + min(t0 + lcol, W - 1));
+                } while (!__all((g >> 32) == c.tag_in));
+                c.wait_in += spins.n;
+            }
+            const int gD = (int)((unsigned)g >> 2);
+            const int gV = gD + (int)((unsigned)g & 3u);
+            c.gbatch = load_granule(c.gin + min(t0 + kGranCols + lcol, W - 1));
+            const int Dm1 = shift_down1(c.carryD, gD);
+            c.carryD = __builtin_amdgcn_readlane(gD, kGranCols - 1);
+            if (kGranCols == 64 || lane < kGranCols) c.my_ring[slot0 + lane] = make_int2(Dm1, gV);
         }
     } else if (MODE == kFast || MODE == kHead || t0 < W) {
         // (unconditional in the steady state, also in its blocks past the last column, where col_ok is
@@ -464,8 +495,11 @@ __device__ __forceinline__ bool run_steady(StripCtx<CODES>& c, FillLds& lds, con
         if (!run_superblock<CODES, kHead, IN, OUT>(c, lds, p, 0)) return false;
         lo = 1;
     }
+    if (IN == kInHbm && kGranCols > kBlk)   // first batch of the steady state
+        c.gbatch = load_granule(c.gin + min(64 * lo + (c.lane & (kGranCols - 1)), c.W - 1));
     for (int sb = lo; sb < hi; ++sb)
         if (!run_superblock<CODES, kFast, IN, OUT>(c, lds, p, sb)) return false;
+    if (IN == kInHbm && kGranCols > kBlk) c.gq_valid = 0;   // the tail fetches for itself
     return true;
 }
 
@@ -499,6 +533,9 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     const int64_t strips = (R + 63) >> 6;
     const int64_t s = (int64_t)__builtin_amdgcn_readfirstlane(wg_ticket) * kNW + wv;  // strip inside the chunk
     if (s >= strips) return;
+#ifdef PSA_FILL_STATS   // experiment: time a workgroup sits on its CU before / while it works (control block words 48..)
+    const unsigned long long st_entry = wall_clock64();
+#endif
     const int64_t row_base = p.r0 + 64 * s;
     const int64_t sg = c.sg = row_base >> 6;
     const int64_t i = c.i = row_base + lane + 1;
@@ -560,6 +597,7 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     if (u64* co = ckpt_row_out(p, sg)) c.gout = co;           // the checkpoint rows, not the ring
     c.carryD = D_up;          // D of column t0-1 of the row above (wave 0 path)
     for (int j = 0; j < kGDist; ++j) c.gq[j] = 0;
+    c.gbatch = 0;
     c.gq_valid = 0;
     c.wait_in = c.wait_room = 0;
 
@@ -591,6 +629,9 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
             }
         }
     }
+#ifdef PSA_FILL_STATS
+    const unsigned long long st_start = wall_clock64();
+#endif
     if (p.prof && lane == 0) {
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -631,6 +672,14 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
         }
     }
 
+#ifdef PSA_FILL_STATS
+    if (lane == 0) {
+        const unsigned long long st_end = wall_clock64();
+        unsigned long long* stats = (unsigned long long*)(p.ticket + 48);
+        if (wv == 0) { atomicAdd(stats + 0, st_start - st_entry); atomicAdd(stats + 1, st_end - st_start); }
+        if (wv == kNW - 1 || s == strips - 1) atomicAdd(stats + 2, st_end - st_entry);
+    }
+#endif
     if (p.prof && lane == 0) {
         p.prof[4 * s + 1] = wall_clock64();
         p.prof[4 * s + 3] = ((u64)c.wait_room << 32) | c.wait_in;

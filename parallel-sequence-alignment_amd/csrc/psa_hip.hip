@@ -340,6 +340,16 @@ static int check_abort(psa_stripe* s, hipStream_t st) {
     unsigned ctrl[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(ctrl, s->ctrl, sizeof ctrl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+#ifdef PSA_FILL_STATS
+    {
+        unsigned long long stats[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(stats, s->ctrl + 48, sizeof stats, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (getenv("PSA_FILL_STATS") && ctrl[0])
+            fprintf(stderr, "fillstats: groups %u wait_before_start_us %.1f wave0_work_us %.1f wg_resident_us %.1f (means per group)\n",
+                    ctrl[0], stats[0] / 100.0 / ctrl[0], stats[1] / 100.0 / ctrl[0], stats[2] / 100.0 / ctrl[0]);
+    }
+#endif
     if (ctrl[1]) return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired");
     return PSA_OK;
 }
