@@ -283,16 +283,35 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     const bool to_hbm = (OUT == kAny) ? c.to_hbm : (OUT == kOutHbm);
     // ---- 1. lane 0's inputs for columns t0..t0+15: ring slots t0+64..t0+79 ----
     const int slot0 = (t0 + 64) & (kRing - 1);
+    const int4* rp = (const int4*)(c.my_ring + slot0);
+    int4 pre[8];
+    bool pre_loaded = false;
     if (from_lds) {
         if (MODE == kFast || MODE == kHead || t0 < W) {   // (no run-time condition in the steady state)
             // slots t0+64..t0+79 are complete once the producer has finished step t0+78; it stops at nblocks*16
             const int need = min(t0 + 80, c.nblocks * kBlk);
             if (c.prod_seen < need) {
-                Spin spins;
-                while ((c.prod_seen = __builtin_amdgcn_readfirstlane(lds_peek(&lds.prod[c.wv]))) < need) {
-                    if (spin_expired(spins, p.abort_flag)) return false;
+                // A strip runs right behind the one above, so it has to look at the progress counter in
+                // nearly every block.  The look and the reads of the slots go out together: LDS performs
+                // them in order, so if the counter (read first) says "complete", the slot values read
+                // after it are the complete ones -- one LDS round trip per block instead of two.
+                int pk = lds_peek(&lds.prod[c.wv]);
+                PSA_COMPILER_BARRIER();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pre[j] = rp[j];
+                asm volatile("" : "+v"(pk) : : "memory");   // (keeps the wait for the counter behind the issue of the reads)
+                c.prod_seen = __builtin_amdgcn_readfirstlane(pk);
+                pre_loaded = true;
+                if (c.prod_seen < need) {
+                    Spin spins;
+                    while ((c.prod_seen = __builtin_amdgcn_readfirstlane(lds_peek(&lds.prod[c.wv]))) < need) {
+                        if (spin_expired(spins, p.abort_flag)) return false;
+                    }
+                    c.wait_in += spins.n;
+                    PSA_COMPILER_BARRIER();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pre[j] = rp[j];
                 }
-                c.wait_in += spins.n;
             }
         }
     } else if (MODE == kFast && IN == kInHbm && kGranCols > kBlk) {
@@ -384,10 +403,10 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
         // first block of wave 0 (t0 = 0), its input has arrived: move the front (see the kernel's prologue)
         if (lane == 0) __hip_atomic_fetch_max(p.ticket + kFrontWord, (unsigned)c.wg + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const int4* rp = (const int4*)(c.my_ring + slot0);
-    int4 pre[8];
+    if (!pre_loaded) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pre[j] = rp[j];
+        for (int j = 0; j < 8; ++j) pre[j] = rp[j];
+    }
     if (IN == kAny || IN == kInLds) lds_post(c.cons_post, t0 + 80);
 
     int* pa = c.out_base + (c.out_wrap ? ((2 * t0) & (c.out_wrap - 1)) : 0);
