@@ -189,6 +189,12 @@ def single_gpu(args):
         [x.join() for x in th]
         return res, fill_ms, tb_ms
 
+    # first use of every slot's stream on its own: creating a hardware queue (and, under rocprofv3, its
+    # interception) while fills of other slots are running was seen to freeze those fills for seconds
+    _ai = np.zeros(cap, np.int32); _bj = np.zeros(cap, np.int32)
+    for st_, sm_ in zip(stripes, streams):
+        one_alignment(st_, sm_.cuda_stream, _ai, _bj)
+    torch.cuda.synchronize()
     run_steps(args.warmup, 0.004)
     torch.cuda.synchronize()
     stagger = 0.004

@@ -337,7 +337,7 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
 extern "C" {
 
 static int check_abort(psa_stripe* s, hipStream_t st) {
-    unsigned ctrl[2] = {0, 0};
+    unsigned ctrl[40] = {0};
     HIP_TRY(hipMemcpyAsync(ctrl, s->ctrl, sizeof ctrl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
 #ifdef PSA_FILL_STATS
@@ -350,7 +350,9 @@ static int check_abort(psa_stripe* s, hipStream_t st) {
                     ctrl[0], stats[0] / 100.0 / ctrl[0], stats[1] / 100.0 / ctrl[0], stats[2] / 100.0 / ctrl[0]);
     }
 #endif
-    if (ctrl[1]) return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired");
+    if (ctrl[1])
+        return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired (workgroups started %u, "
+                    "chain front at workgroup %u)", ctrl[0], ctrl[psa::kFrontWord]);
     return PSA_OK;
 }
 
