@@ -96,10 +96,10 @@ __global__ void build_eqtab(const uint8_t* b, int W, const unsigned* meta, const
 }
 
 // ---- per-workgroup LDS ----
-struct __attribute__((aligned(16))) FillLds {
+struct __attribute__((aligned(128))) FillLds {
     int2 ring[kNW][kRing];       // ring[w]: input of wave w; slot s = (D of column s-65, V of column s-64)
     int2 stage[kNW][32];         // staging of a wave's last row on its way to HBM granules
-    int dummy[kNW][64 + 48];     // where lanes other than 63 drop their publish writes
+    int dummy[kNW][128];         // where lanes other than 63 drop their publish writes (row = 32 banks x 4; see out_base)
     int dummy2[kNW][64];         // where lanes that own no counter drop their counter posts
     int prod[kNW];               // steps completed by the producer of ring[w]
     int cons[kNW];               // ring[w] slots below this number have been read
@@ -604,7 +604,10 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     c.my_ring = lds.ring[wv];
     if (lane == 63 && c.to_lds) { c.out_base = (int*)lds.ring[wv + 1]; c.out_wrap = kRing * 2; }
     else if (lane == 63 && c.to_hbm) { c.out_base = (int*)lds.stage[wv]; c.out_wrap = 32 * 2; }
-    else { c.out_base = lds.dummy[wv] + lane; c.out_wrap = 0; }
+    // (lane l's dump address is 1 + l past a 32-bank boundary: the one bank lanes 32..62 leave free in a
+    // write is then the bank of lane 63's real slot -- ring and staging rows start on a bank boundary and
+    // move by the same 2 dwords per step -- instead of that write colliding with one of theirs every step)
+    else { c.out_base = lds.dummy[wv] + 1 + lane; c.out_wrap = 0; }
     c.prod_post = (lane == 63 && c.to_lds) ? &lds.prod[wv + 1] : &lds.dummy2[wv][lane];
     c.cons_post = (lane == 0 && c.from_lds) ? &lds.cons[wv] : &lds.dummy2[wv][lane];
     c.tag_in = (u64)sg;
