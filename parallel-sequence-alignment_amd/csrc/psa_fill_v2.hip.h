@@ -246,6 +246,8 @@ struct StripCtx {
     int msh, mword_idx;
     unsigned mw[17];        // table words covering this superblock's 64 columns (+ alignment spill)
     int prod_seen;          // (u) last value read from the producer's counter
+    int cons_seen;          // (u) last value looked at of the consumer's counter (producer side)
+    int cons_pending;       // the consumer's counter as requested one superblock ago
     // hand-off
     int2* my_ring;
     int* out_base;
@@ -470,12 +472,23 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
     const u32x4_a4 n2 = *(const u32x4_a4*)(c.trow + c.mword_idx + 25);
     const u32x4_a4 n3 = *(const u32x4_a4*)(c.trow + c.mword_idx + 29);
     // room in the consumer's ring for the slots this superblock writes (up to t0 + 65)
+    // The consumer trails by ~80 of the ring's 256 slots, so there is room practically always: the
+    // counter is read one superblock ahead of its use (the value is in a register long before it is looked
+    // at) -- read and used on the spot, the LDS round trip, taken right behind the table requests, cost
+    // ~5 cycles of every step.
     if ((OUT == kAny) ? c.to_lds : (OUT == kOutLds)) {
-        Spin spins;
-        while (__builtin_amdgcn_readfirstlane(lds_peek(&lds.cons[c.wv + 1])) < t0 + 66 - kRing) {
-            if (spin_expired(spins, p.abort_flag)) return false;
+        const int need = t0 + 66 - kRing;
+        if (c.cons_seen < need) {
+            c.cons_seen = __builtin_amdgcn_readfirstlane(c.cons_pending);
+            if (c.cons_seen < need) {
+                Spin spins;
+                while ((c.cons_seen = __builtin_amdgcn_readfirstlane(lds_peek(&lds.cons[c.wv + 1]))) < need) {
+                    if (spin_expired(spins, p.abort_flag)) return false;
+                }
+                c.wait_room += spins.n;
+            }
         }
-        c.wait_room += spins.n;
+        c.cons_pending = lds_peek(&lds.cons[c.wv + 1]);
     }
 #define PSA_BLOCK(j)                                                                                   \
     {                                                                                                  \
@@ -599,6 +612,8 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
 #pragma unroll
     for (int j = 0; j < 17; ++j) c.mw[j] = c.trow[c.mword_idx + j];
     c.prod_seen = 0;
+    c.cons_seen = 0;
+    c.cons_pending = 0;
 
     // ---- hand-off plumbing ----
     c.my_ring = lds.ring[wv];
