@@ -170,6 +170,8 @@ def single_gpu(args):
         res, fill_ms, tb_ms = [], [], []
 
         def worker(slot):
+            torch.cuda.set_device(local)   # (the current device is per thread; the library also switches to the stripe's)
+            psa_amd.set_device(local)
             st, stream = stripes[slot], streams[slot].cuda_stream
             ai = np.zeros(cap, np.int32)
             bj = np.zeros(cap, np.int32)

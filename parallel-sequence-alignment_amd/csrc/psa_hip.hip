@@ -100,9 +100,19 @@ struct psa_stripe {
     // was before each band (see align_banded)
     int64_t band_rows = 0;
     psa::u64* ckpt = nullptr;
+    int device = 0;              // the HIP device the stripe lives on (current when it was created)
 };
 
 namespace {
+// The current HIP device is a per-thread setting and a new host thread starts on device 0: every call
+// that works on a stripe first makes the stripe's own device current (callers keep one thread per
+// alignment in flight, bench.py for one).
+int enter_device(const psa_stripe* s) {
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != s->device) HIP_TRY(hipSetDevice(s->device));
+    return PSA_OK;
+}
 // what one fill launch may override (banded mode)
 struct FillOpts {
     int codes = -1;                  // -1: as the stripe was created; 0 / 1: without / with winner codes
@@ -165,6 +175,7 @@ void psa_free(void* p) { free(p); }
 
 void psa_stripe_destroy(psa_stripe* s) {
     if (!s) return;
+    enter_device(s);
     hipFree(s->a_dev); hipFree(s->b_dev); hipFree(s->ring); hipFree(s->codes);
     hipFree(s->a_ids); hipFree(s->alpha); hipFree(s->eqtab);
     hipFree(s->ckpt);
@@ -183,6 +194,7 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
     if (n > (1LL << 27) || m > (1LL << 27)) return fail(PSA_E_ARG, "sequence longer than 2^27 is not supported");
     if (int rc = need_device()) return rc;
     psa_stripe* s = new psa_stripe();
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
     s->n = n; s->m = m; s->c0 = c0; s->c1 = c1; s->flags = flags;
     s->W = (int)(c1 - c0);
     s->Q = (s->W + 63 + 63) / 64;
@@ -232,6 +244,7 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
 
 int psa_stripe_set_sequences_dev(psa_stripe* s, const uint8_t* a_dev, const uint8_t* b_dev, void* stream) {
     if (!s || !a_dev || !b_dev) return fail(PSA_E_ARG, "psa_stripe_set_sequences_dev: null argument");
+    if (int rc = enter_device(s)) return rc;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemcpyAsync(s->a_dev, a_dev, (size_t)s->n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->b_dev, b_dev, (size_t)s->W, hipMemcpyDeviceToDevice, st));
@@ -250,6 +263,7 @@ namespace {
 int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev, void* stream,
                    const FillOpts& o) {
     if (!s) return fail(PSA_E_ARG, "psa_stripe_fill_rows: null stripe");
+    if (int rc = enter_device(s)) return rc;
     if (r0 == 0) s->next_r0 = 0;  // a new pass over the same stripe
     if (o.any_order) s->next_r0 = r0;
     if (r0 != s->next_r0) return fail(PSA_E_STATE, "psa_stripe_fill_rows: chunks out of order (r0=%lld, expected %lld)",
@@ -361,6 +375,7 @@ int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]) {
     if (s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_final: rows filled up to %lld of %lld",
                                         (long long)s->next_r0, (long long)s->n);
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = enter_device(s)) return rc;
     if (int rc = check_abort(s, st)) return rc;
     HIP_TRY(hipMemcpyAsync(triple_out, s->small + 8, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));   // (on the stripe's own stream: the null stream would order it against other stripes' work)
@@ -398,6 +413,7 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     if (*k_io < 1 || *k_io > 3 || *i_io < 0 || *i_io > s->n || *j_io < 0 || *j_io > s->c1 + 1)
         return fail(PSA_E_ARG, "psa_stripe_traceback: bad state (%lld,%lld,%d)", (long long)*i_io, (long long)*j_io, *k_io);
     hipStream_t st = (hipStream_t)stream;
+    if (int rc = enter_device(s)) return rc;
     if (int rc = check_abort(s, st)) return rc;
     int64_t state[12] = {*i_io, *j_io, *k_io, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(s->tb_state, state, sizeof state, hipMemcpyHostToDevice, st));
@@ -442,6 +458,7 @@ extern "C" {
 
 int psa_stripe_last_fill_ms(psa_stripe* s, float* ms_out) {
     if (!s || !ms_out || !s->fill_timed) return fail(PSA_E_STATE, "no fill has been timed");
+    if (int rc = enter_device(s)) return rc;
     HIP_TRY(hipEventSynchronize(s->ev[1]));
     HIP_TRY(hipEventElapsedTime(ms_out, s->ev[0], s->ev[1]));
     return PSA_OK;
@@ -449,6 +466,7 @@ int psa_stripe_last_fill_ms(psa_stripe* s, float* ms_out) {
 
 int psa_stripe_last_traceback_ms(psa_stripe* s, float* ms_out) {
     if (!s || !ms_out || !s->tb_timed) return fail(PSA_E_STATE, "no traceback has been timed");
+    if (int rc = enter_device(s)) return rc;
     HIP_TRY(hipEventSynchronize(s->ev[3]));
     HIP_TRY(hipEventElapsedTime(ms_out, s->ev[2], s->ev[3]));
     return PSA_OK;
