@@ -13,6 +13,7 @@ namespace psa {
 
 constexpr int kBatchWaves = 4;      // waves per workgroup
 constexpr int kBatchMaxLen = 1024;  // longest B the LDS row buffer holds; longer pairs use psa_score
+constexpr int32_t kBatchSkipped = INT32_MIN;   // score slot of a pair the kernel did not align (B longer than max_b)
 
 struct BatchArgs {
     const uint8_t* seqs;
@@ -47,6 +48,13 @@ __global__ __launch_bounds__(kBatchWaves * 64) void batch_score_kernel(BatchArgs
         const uint8_t* B = p.seqs + p.offsets[sb];
         const int nA = (int)(p.offsets[sa + 1] - p.offsets[sa]);
         const int nB = (int)(p.offsets[sb + 1] - p.offsets[sb]);
+        if (nB > p.max_b) {
+            // the per-wave row and B buffers are sized from max_b: a longer pair would write into the next
+            // wave's buffers.  Not aligned here: the score is marked missing and the caller goes through
+            // psa_score (psa_score_batch does; psa_score_batch_dev documents the sentinel).
+            if (lane == 0) p.scores[pair] = kBatchSkipped;
+            continue;
+        }
         if (nA == 0 || nB == 0) {
             // no cell: the final pick reads the boundary (simple.cpp:246 after an empty loop / column 0 only)
             if (lane == 0) p.scores[pair] = (nA == 0) ? 0 : -1;

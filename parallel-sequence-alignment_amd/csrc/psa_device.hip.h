@@ -26,6 +26,7 @@ constexpr int kSubMismatch = 6;  // 0 + 2*3 (a diagonal step raises the bias by 
 constexpr int kSubMatch = 8;     // 2 + 2*3
 
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __host__ __forceinline__ int max3i_hd(int a, int b, int c) { const int m = a > b ? a : b; return m > c ? m : c; }
 
 // DPP wave_shr:1 -- lane l receives src of lane l-1; lane 0 keeps `old`.
 __device__ __forceinline__ int shift_down1(int old, int src) {
@@ -48,37 +49,56 @@ __device__ __host__ __forceinline__ int winner_plain(int t1, int t2, int t3, int
     return t2 >= t3 ? 2 : 3;
 }
 
-// Packed winner codes: per strip (64 rows), per block of 64 wavefront steps ("tile"), three parts,
-// per lane, four dwords (48 bytes per lane and tile = 0.75 byte per cell):
-//   part 0, 1: eight words of eight 4-bit steps; word u>>3 holds step u (0..63) in bits 4*(7-(u&7))..+3
-//              as nibble 2*(q'+3) + b1_D, q' = clamp(x2 - x3, -3, 2), b1_D = (x1 == D), AFTER
-//              kCodeBias has been added to the stored word (the writer accumulates signed q')
-//   part 2:    dwords 0,1: b1_H = (x1 == H') of steps 0..31 / 32..63, step u in bit 31-(u&31);
-//              dwords 2,3: b1_V = (x1 == V') likewise
-// The three "table 2 before table 3" bits follow from q' = x2 - x3 clamped:
-//   D: x2 >= x3  <=> q' >= 0;   H': x2 + 2 >= x3  <=> q' >= -2;   V': x2 >= x3 + 2  <=> q' >= 2.
-constexpr uint32_t kCodeBias = 0x66666666u;
+// Winner codes, one byte per cell (the "traceback stream", 1 B per cell):
+//     byte = ((D & 15) << 4) | ((H' - D) << 2) | (V' - D)          H' - D and V' - D are in {0, 1, 2}
+// which is (11*D + 4*H' + V') & 0xff: two instructions (v_lshl_add_u32, v_mad_u32_u24) and one
+// v_alignbit_b32 to shift the byte into the word being collected.  The traceback of a cell p needs
+// the three values the reference compared there (simple.cpp:162/166/170),
+//     x1(p) = D(diag) + (6 | 8),   x2(p) = H'(left),   x3(p) = V'(up)      (biased domain)
+// only relative to each other.  All three lie within 8 below D(p) (D - x2 <= (D(p) - D(left)) + 3,
+// horizontal and vertical neighbours of D differ by -3..+5 in the plain domain, diagonal ones by
+// 0..2: the bounds of the Gotoh recurrence, checked exhaustively in tests/test_oracle.py), so the
+// low four bits of D of p's three neighbours and of p itself decide every comparison:
+//     e_k = (D(p) - x_k(p)) & 15     in 0..8, and min(e1, e2, e3) == 0.
+// Storage: per strip (64 rows), per block of 64 wavefront steps one 4 KB tile, [part 0..3][lane][16 bytes]:
+// step u of lane l sits at byte ((u >> 4) * 64 + l) * 16 + (u & 15); a wavefront stores 4 x 1 KB per
+// 64 steps, 16 bytes per lane, fully coalesced although the lanes sit on different columns.
+constexpr int kTileBytes = 4096;
 
-__device__ __host__ __forceinline__ int64_t code_word_index(int64_t strip, int64_t qblocks, int64_t q,
-                                                            int part, int lane, int d) {
-    return ((((strip * qblocks + q) * 3 + part) * 64 + lane) * 4) + d;
+__device__ __host__ __forceinline__ int64_t code_tile_offset(int64_t strip, int64_t qblocks, int64_t q) {
+    return (strip * qblocks + q) * (int64_t)kTileBytes;
 }
-// word offsets inside one tile ([part][lane][4] dwords) of step u's nibble word and b1_H / b1_V word
-__device__ __host__ __forceinline__ int code_q_offset(int lane, int u) { return ((u >> 5) * 64 + lane) * 4 + ((u >> 3) & 3); }
-__device__ __host__ __forceinline__ int code_hv_offset(int lane, int u, int kind) {
-    return (2 * 64 + lane) * 4 + (kind == 3 ? 2 : 0) + (u >> 5);
+__device__ __host__ __forceinline__ int code_byte_offset(int lane, int u) {
+    return (((u >> 4) * 64 + lane) << 4) + (u & 15);
 }
-// winner (1, 2 or 3) for aggregate `kind` (1 = D, 2 = H', 3 = V') from step u's words
-__device__ __host__ __forceinline__ int code_winner(uint32_t qword, uint32_t hvword, int u, int kind) {
-    const unsigned nib = ((qword + kCodeBias) >> (4 * (7 - (u & 7)))) & 15u;
-    const unsigned q3 = nib >> 1;   // q' + 3, 0..5
-    bool b1, b23;
-    if (kind == 1) { b1 = nib & 1u; b23 = q3 >= 3; }
-    else {
-        b1 = (hvword >> (31 - (u & 31))) & 1u;
-        b23 = (kind == 2) ? (q3 >= 1) : (q3 >= 5);
-    }
-    return b1 ? 1 : (b23 ? 2 : 3);
+__device__ __host__ __forceinline__ unsigned code_byte(int D, int Hn, int Vn) {
+    return (unsigned)(11 * D + 4 * Hn + Vn) & 0xffu;
+}
+// Winner (1, 2 or 3) for aggregate `kind` (1 = D, 2 = H', 3 = V') at a cell whose own D and whose three
+// inputs are known modulo 16.  *bad is set when the values cannot belong to one cell (decode check).
+__device__ __host__ __forceinline__ int winner_mod16(int dp, int x1, int x2, int x3, int kind, int* bad) {
+    int e1 = (dp - x1) & 15, e2 = (dp - x2) & 15, e3 = (dp - x3) & 15;
+    if (bad && (e1 > 2 || e2 > 8 || e3 > 8 || (e1 && e2 && e3))) *bad = 1;
+    if (kind == 2) e2 -= 2; else if (kind == 3) e3 -= 2;
+    if (e1 <= e2 && e1 <= e3) return 1;   // x1 >= x2' && x1 >= x3'
+    return e2 <= e3 ? 2 : 3;
+}
+// Biased boundary values of the reference (row 0 / column 0; psa_device boundary_triple + 3*(i+j)):
+// D, H' of column 0 and D, V' of row 0.
+__device__ __host__ __forceinline__ int boundary_D(int64_t i, int64_t j) {
+    int t1, t2, t3;
+    boundary_triple(i, j, t1, t2, t3);
+    return max3i_hd(t1, t2, t3) + (int)(3 * (i + j));
+}
+__device__ __host__ __forceinline__ int boundary_Hn(int64_t i, int64_t j) {
+    int t1, t2, t3;
+    boundary_triple(i, j, t1, t2, t3);
+    return max3i_hd(t1, t2 + 2, t3) + (int)(3 * (i + j));
+}
+__device__ __host__ __forceinline__ int boundary_Vn(int64_t i, int64_t j) {
+    int t1, t2, t3;
+    boundary_triple(i, j, t1, t2, t3);
+    return max3i_hd(t1, t2, t3 + 2) + (int)(3 * (i + j));
 }
 
 }  // namespace psa

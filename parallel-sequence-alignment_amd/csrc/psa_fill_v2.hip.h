@@ -105,37 +105,20 @@ struct __attribute__((aligned(128))) FillLds {
     int cons[kNW];               // ring[w] slots below this number have been read
 };
 
-// Winner bits of one cell (layout: psa_device.hip.h, "packed winner codes").  Per step:
-//   aQ = 16*aQ + 2*q' + (x1 == D)      q' = clamp(x2 - x3, -3, 2): all three "table 2 before table 3"
-//                                      bits at once (x2 >= x3, x2 + 2 >= x3, x2 >= x3 + 2)
-//   aH = 2*aH + (x1 == H'),  aV = 2*aV + (x1 == V')
-// Three compares, the clamp, then the adds: every SGPR written by a v_cmp is read at least five
-// instructions later (gfx950 needs two wait states between them).  q' is signed; eight steps sum
-// to the word of non-negative nibbles minus 0x66666666, which the reader adds back.
-__device__ __forceinline__ void push_bits(unsigned& aQ, unsigned& aH, unsigned& aV, int x1, int x2, int x3,
-                                          int D, int Hn, int Vn) {
-    unsigned long long s0, s1, s2;
-    int qd;
-    asm volatile(
-        "v_cmp_eq_i32_e64 %[s0], %[x1], %[D]\n\t"
-        "v_cmp_eq_i32_e64 %[s1], %[x1], %[Hn]\n\t"
-        "v_cmp_eq_i32_e64 %[s2], %[x1], %[Vn]\n\t"
-        "v_sub_u32_e32 %[qd], %[x2], %[x3]\n\t"
-        "v_med3_i32 %[qd], %[qd], -3, 2\n\t"
-        "v_lshl_add_u32 %[aQ], %[aQ], 3, %[qd]\n\t"
-        "v_addc_co_u32_e64 %[aQ], %[s0], %[aQ], %[aQ], %[s0]\n\t"
-        "v_addc_co_u32_e64 %[aH], %[s1], %[aH], %[aH], %[s1]\n\t"
-        "v_addc_co_u32_e64 %[aV], %[s2], %[aV], %[aV], %[s2]"
-        : [aQ] "+v"(aQ), [aH] "+v"(aH), [aV] "+v"(aV), [s0] "=&s"(s0), [s1] "=&s"(s1), [s2] "=&s"(s2),
-          [qd] "=&v"(qd)
-        : [x1] "v"(x1), [x2] "v"(x2), [x3] "v"(x3), [D] "v"(D), [Hn] "v"(Hn), [Vn] "v"(Vn));
+// Winner code of one cell (layout: psa_device.hip.h, "winner codes"): the byte (11*D + 4*H' + V') & 0xff
+// enters the word being collected from the top; four steps fill a word.
+__device__ __forceinline__ void push_code(unsigned& acc, int D, int Hn, int Vn) {
+    unsigned t;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(t) : "v"(Hn), "v"(Vn));
+    asm("v_mad_u32_u24 %0, %1, 11, %2" : "=v"(t) : "v"(D), "v"(t));
+    acc = __builtin_amdgcn_alignbit(t, acc, 8);
 }
 
 struct StripState {
     int D0, D1;   // D of this row after the last even / odd step
     int H;        // H' of this row (x2 of the next column)
     int V;        // V' of this row at its current column (x3 of the row below)
-    unsigned aQ, aH, aV;   // winner-bit accumulators (push_bits)
+    unsigned acc;          // winner codes of the last four steps (push_code)
     int r1, r2, r3;  // x1, x2, x3 of this row at the stripe's last column (captured in the tail)
 };
 
@@ -174,7 +157,7 @@ __device__ __forceinline__ void step16(const int k, StripState& S, const int4& p
     const int D = max3i(x1, x2, x3);
     const int Hn = max(D, x2p);
     const int Vn = max(D, x3p);
-    if (CODES) push_bits(S.aQ, S.aH, S.aV, x1, x2, x3, D, Hn, Vn);
+    if (CODES) push_code(S.acc, D, Hn, Vn);
     if (MODE == kTail || MODE == kGeneric) {
         if (lane == t - (W - 1)) { S.r1 = x1; S.r2 = x2; S.r3 = x3; }
     }
@@ -262,7 +245,7 @@ struct StripCtx {
     u64 gbatch;             // steady state, kGranCols > 16: the next kGranCols granules, one per lane
     u64 gq[kGDist];         // granules requested kGDist blocks ahead (wave 0 path), by block index mod kGDist
     unsigned gq_valid;      // (u) bit j: gq[j] holds a request
-    unsigned qd[8], hv[4];  // winner-bit words of the current superblock (see run_superblock)
+    unsigned qd[16];        // winner codes of the current superblock (see run_superblock)
     unsigned wait_in, wait_room;  // (u) spin iterations, for the profile only
 };
 
@@ -432,8 +415,10 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
 
     // ---- 2. the sixteen steps ----
 #pragma unroll
-    for (int k = 0; k < kFlushAt; ++k)
+    for (int k = 0; k < kFlushAt; ++k) {
         step16<CODES, MODE>(k, c.S, pre[k >> 1], mq[k >> 2], pa, pb, t0 + k, lane, W, c.row_ok);
+        if (CODES && (k & 3) == 3) c.qd[4 * JB + (k >> 2)] = c.S.acc;
+    }
     if (OUT == kAny || OUT == kOutHbm) {
         const u64 gran = (c.tag_out << 32) | ((unsigned)fd << 2) | (unsigned)(fv - fd);
         if (flush_always) {
@@ -451,7 +436,7 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
 #pragma unroll
     for (int k = kFlushAt; k < kBlk; ++k) {
         step16<CODES, MODE>(k, c.S, pre[k >> 1], mq[k >> 2], pa, pb, t0 + k, lane, W, c.row_ok);
-        if (CODES && (k & 7) == 7) c.qd[2 * JB + (k >> 3)] = c.S.aQ;   // eight 4-bit steps fill a word
+        if (CODES && (k & 3) == 3) c.qd[4 * JB + (k >> 2)] = c.S.acc;   // four steps fill a word
     }
 
     // ---- 3. publish progress ----
@@ -500,16 +485,15 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
     }
     PSA_BLOCK(0)
     PSA_BLOCK(1)
-    if (CODES) { c.hv[0] = c.S.aH; c.hv[2] = c.S.aV; }   // 32 one-bit steps each
     PSA_BLOCK(2)
     PSA_BLOCK(3)
-    if (CODES) { c.hv[1] = c.S.aH; c.hv[3] = c.S.aV; }
 #undef PSA_BLOCK
     if (CODES) {
-        uint4* dst = (uint4*)(p.codes + code_word_index(c.sg, p.Q, sb, 0, c.lane, 0));
+        uint4* dst = (uint4*)(p.codes + code_tile_offset(c.sg, p.Q, sb)) + c.lane;
         dst[0] = make_uint4(c.qd[0], c.qd[1], c.qd[2], c.qd[3]);
         dst[64] = make_uint4(c.qd[4], c.qd[5], c.qd[6], c.qd[7]);
-        dst[128] = make_uint4(c.hv[0], c.hv[1], c.hv[2], c.hv[3]);
+        dst[128] = make_uint4(c.qd[8], c.qd[9], c.qd[10], c.qd[11]);
+        dst[192] = make_uint4(c.qd[12], c.qd[13], c.qd[14], c.qd[15]);
     }
     c.mw[0] = c.mw[16];
     c.mw[1] = n0.x; c.mw[2] = n0.y; c.mw[3] = n0.z; c.mw[4] = n0.w;
@@ -599,8 +583,9 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     const int D_up = max3i(u1, u2, u3) + bias_own - 3;
     c.S.D0 = c.S.D1 = D_own;
     c.S.H = max3i(o1, o2 + 2, o3) + bias_own;
+    if (CODES && p.leftcol && row_ok) p.leftcol[i] = make_int2(D_own, c.S.H);
     c.S.V = 0;
-    c.S.aQ = c.S.aH = c.S.aV = 0;
+    c.S.acc = 0;
     c.S.r1 = c.S.r2 = c.S.r3 = 0;
     c.y_row = i - p.r0 - 1;
 

@@ -55,14 +55,19 @@ int pick3(const int32_t t[3], int32_t* v) {
     return 3;
 }
 
-constexpr size_t kCtrlBytes = 256;
+// control block: bytes 0..255 are per launch (ticket, front, statistics), bytes 256..511 per pass (the abort
+// flag: a hand-off wait that expired in ANY chunk of the pass stays visible until the pass is over)
+constexpr size_t kSeqPad = 64;
+constexpr size_t kCtrlLaunchBytes = 256;
+constexpr size_t kCtrlBytes = 512;
+constexpr int kAbortWord = 64;
 
 // rows per band in banded mode: PSA_BAND_ROWS, else as many strips as 8 GiB of codes hold
 thread_local int64_t g_band_rows_request = 0;   // set by psa_align_banded around the stripe's creation
 int64_t band_rows_for(int64_t n, int Q) {
     int64_t want = g_band_rows_request;
     if (want <= 0) if (const char* e = getenv("PSA_BAND_ROWS")) want = atoll(e);
-    if (want <= 0) want = 64 * std::max<int64_t>(1, (8LL << 30) / ((int64_t)Q * 3072));
+    if (want <= 0) want = 64 * std::max<int64_t>(1, (8LL << 30) / ((int64_t)Q * psa::kTileBytes));
     const int64_t wg_rows = 64 * psa::kNW;   // band boundaries coincide with workgroup boundaries
     want = std::max<int64_t>(wg_rows, ((want + wg_rows - 1) / wg_rows) * wg_rows);
     return std::min<int64_t>(want, ((n + wg_rows - 1) / wg_rows) * wg_rows);
@@ -75,12 +80,14 @@ struct psa_stripe {
     int W = 0, Q = 0, Wpad = 0;
     uint32_t flags = 0;
     uint8_t* a_dev = nullptr;
-    uint8_t* b_dev = nullptr;
+    uint8_t* b_dev = nullptr;    // = b_alloc + kSeqPad: the traceback's residue windows start up to 64 bytes in front
+    uint8_t* b_alloc = nullptr;
     psa::u64* ring = nullptr;
-    uint32_t* codes = nullptr;
+    uint8_t* codes = nullptr;    // winner codes, one byte per cell in 4 KB tiles (psa_device.hip.h)
+    int2* leftcol = nullptr;     // c0 > 0: (D, H') of column c0 per row, kept for the traceback
     size_t code_bytes = 0;
     int32_t* small = nullptr;    // corner A[3] (pad 4), corner B[3] (pad 4), final[3] (pad 4)
-    unsigned* ctrl = nullptr;    // [0] ticket, [1] abort
+    unsigned* ctrl = nullptr;    // [0] ticket, [32] front, [64] abort flag (kCtrlBytes)
     int32_t* tb_ai = nullptr;
     int32_t* tb_bj = nullptr;
     int64_t tb_cap = 0;
@@ -117,7 +124,7 @@ int enter_device(const psa_stripe* s) {
 struct FillOpts {
     int codes = -1;                  // -1: as the stripe was created; 0 / 1: without / with winner codes
     int W = 0;                       // > 0: only the stripe's first W columns
-    uint32_t* codes_base = nullptr;  // where strip 0's codes would lie
+    uint8_t* codes_base = nullptr;   // where strip 0's codes would lie
     bool any_order = false;          // do not insist on r0 == end of the previous chunk
 };
 int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev, void* stream,
@@ -176,7 +183,7 @@ void psa_free(void* p) { free(p); }
 void psa_stripe_destroy(psa_stripe* s) {
     if (!s) return;
     enter_device(s);
-    hipFree(s->a_dev); hipFree(s->b_dev); hipFree(s->ring); hipFree(s->codes);
+    hipFree(s->a_dev); hipFree(s->b_alloc); hipFree(s->ring); hipFree(s->codes); hipFree(s->leftcol);
     hipFree(s->a_ids); hipFree(s->alpha); hipFree(s->eqtab);
     hipFree(s->ckpt);
     hipFree(s->small); hipFree(s->ctrl); hipFree(s->tb_ai); hipFree(s->tb_bj); hipFree(s->tb_state);
@@ -209,8 +216,10 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
                         "%s failed: %s", #expr, hipGetErrorString(e_));           \
         }                                                                         \
     } while (0)
-    CREATE_TRY(hipMalloc(&s->a_dev, (size_t)n));
-    CREATE_TRY(hipMalloc(&s->b_dev, (size_t)s->W));
+    // (both padded: the traceback fetches whole 64-row / 128-column residue windows beside each code tile)
+    CREATE_TRY(hipMalloc(&s->a_dev, (size_t)n + 2 * kSeqPad));
+    CREATE_TRY(hipMalloc(&s->b_alloc, (size_t)s->W + 4 * kSeqPad));
+    s->b_dev = s->b_alloc + kSeqPad;
     CREATE_TRY(hipMemcpy(s->a_dev, a, (size_t)n, hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(s->b_dev, b + c0, (size_t)s->W, hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(&s->ring, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64)));  // + dump slots, see fill_strips_v2
@@ -224,8 +233,9 @@ int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8
             const int64_t nbands = (n + s->band_rows - 1) / s->band_rows;
             CREATE_TRY(hipMalloc(&s->ckpt, sizeof(psa::u64) * (size_t)(nbands + 1) * (size_t)s->Wpad));
         }
-        s->code_bytes = (size_t)code_strips * (size_t)s->Q * 3 * 64 * 4 * sizeof(uint32_t);
+        s->code_bytes = (size_t)code_strips * (size_t)s->Q * psa::kTileBytes;
         CREATE_TRY(hipMalloc(&s->codes, s->code_bytes));
+        if (c0 > 0) CREATE_TRY(hipMalloc(&s->leftcol, sizeof(int2) * (size_t)(n + 1)));
         s->tb_cap = n + s->W + 2;
         CREATE_TRY(hipMalloc(&s->tb_ai, sizeof(int32_t) * (size_t)s->tb_cap));
         CREATE_TRY(hipMalloc(&s->tb_bj, sizeof(int32_t) * (size_t)s->tb_cap));
@@ -281,8 +291,9 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
         // (A banded refill takes its input from the checkpoint row, never from the ring.)
         HIP_TRY(hipMemsetAsync(s->ring, 0, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64), st));
         if (r0 == 0) s->corner_cur = 0;
+        HIP_TRY(hipMemsetAsync(s->ctrl + kAbortWord, 0, kCtrlBytes - kCtrlLaunchBytes, st));
     }
-    HIP_TRY(hipMemsetAsync(s->ctrl, 0, kCtrlBytes, st));
+    HIP_TRY(hipMemsetAsync(s->ctrl, 0, kCtrlLaunchBytes, st));
     psa::FillArgs fa;
     fa.a = s->a_dev; fa.b = s->b_dev; fa.n = s->n; fa.r0 = r0; fa.r1 = r1; fa.c0 = s->c0;
     fa.W = o.W > 0 ? o.W : s->W; fa.Q = o.W > 0 ? (o.W + 63 + 63) / 64 : s->Q; fa.Wpad = s->Wpad;
@@ -294,8 +305,9 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
     fa.final_triple = s->small + 8;
     fa.ring = s->ring;
     fa.codes = with_codes ? (o.codes_base ? o.codes_base : s->codes) : nullptr;
+    fa.leftcol = with_codes ? s->leftcol : nullptr;
     fa.ticket = s->ctrl;
-    fa.abort_flag = s->ctrl + 1;
+    fa.abort_flag = s->ctrl + kAbortWord;
     fa.prof = nullptr;
     fa.ckpt = s->ckpt; fa.band_strips = s->band_rows / 64;
     const char* prof_path = getenv("PSA_PROFILE_STRIPS");
@@ -351,7 +363,7 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
 extern "C" {
 
 static int check_abort(psa_stripe* s, hipStream_t st) {
-    unsigned ctrl[40] = {0};
+    unsigned ctrl[kAbortWord + 1] = {0};
     HIP_TRY(hipMemcpyAsync(ctrl, s->ctrl, sizeof ctrl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
 #ifdef PSA_FILL_STATS
@@ -364,7 +376,7 @@ static int check_abort(psa_stripe* s, hipStream_t st) {
                     ctrl[0], stats[0] / 100.0 / ctrl[0], stats[1] / 100.0 / ctrl[0], stats[2] / 100.0 / ctrl[0]);
     }
 #endif
-    if (ctrl[1])
+    if (ctrl[kAbortWord])
         return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired (workgroups started %u, "
                     "chain front at workgroup %u)", ctrl[0], ctrl[psa::kFrontWord]);
     return PSA_OK;
@@ -386,7 +398,7 @@ int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]) {
 
 namespace {
 struct TraceOpts {
-    const uint32_t* codes_base = nullptr;   // banded mode: where strip 0's codes would lie
+    const uint8_t* codes_base = nullptr;    // banded mode: where strip 0's codes would lie
     int W = 0;                              // > 0: the codes were written by a fill of the first W columns
     int64_t row_min = 0;                    // the codes cover rows > row_min only
 };
@@ -419,13 +431,16 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     HIP_TRY(hipMemcpyAsync(s->tb_state, state, sizeof state, hipMemcpyHostToDevice, st));
     psa::TraceArgs ta;
     ta.codes = o.codes_base ? o.codes_base : s->codes; ta.c0 = s->c0; ta.cap = s->tb_cap;
+    ta.a = s->a_dev; ta.b = s->b_dev; ta.leftcol = s->leftcol;
+    ta.toprow = (o.row_min > 0 && s->band_rows > 0) ? s->ckpt + (size_t)(o.row_min / s->band_rows) * (size_t)s->Wpad : nullptr;
+    if (o.row_min > 0 && !ta.toprow) return fail(PSA_E_STATE, "traceback: a row limit needs the checkpoint row of a banded stripe");
     ta.W = o.W > 0 ? o.W : s->W; ta.Q = o.W > 0 ? (o.W + 63 + 63) / 64 : s->Q;
     ta.row_min = o.row_min;
     ta.out_ai = s->tb_ai; ta.out_bj = s->tb_bj; ta.state = s->tb_state;
     HIP_TRY(hipEventRecord(s->ev[2], st));
     {
         const char* force = getenv("PSA_TRACEBACK_KERNEL");
-        // the fast kernels keep the walk in 32-bit registers: coordinates and tile ids must fit
+        // the fast kernel keeps the walk in 32-bit registers: coordinates and tile ids must fit
         const bool fits32 = s->n < 0x7fff0000LL && s->c0 + s->W < 0x7fff0000LL &&
                             ((s->n + 63) / 64) * (int64_t)ta.Q < 0x7fff0000LL;
         if ((force && !strcmp(force, "v1")) || !fits32) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
@@ -438,6 +453,7 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     HIP_TRY(hipStreamSynchronize(st));
     if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: len %lld iterations %lld runs/tiles %lld misses %lld\n", (long long)state[4], (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)state[7]);
     if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld; sections %lld %lld %lld %lld\n", (long long)state[8], (long long)state[9], (long long)(state[10] >> 32), (long long)(state[10] & 0xffffffff), (long long)(state[11] >> 32), (long long)(state[11] & 0xffffffff));
+    if (state[5] == 2) return fail(PSA_E_KERNEL, "traceback: winner codes failed the decode check (values that cannot belong to one cell)");
     if (state[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow");
     const int64_t got = state[4];
     if (*len_io + got > cap) return fail(PSA_E_ARG, "psa_stripe_traceback: output capacity %lld too small", (long long)cap);
@@ -571,10 +587,10 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, i
     *len_out = 0;
     const int64_t cap = 2 * (n + m) + 2;
     if (n > 0 && m > 0) {
-        // codes of the whole matrix (0.75 B per cell) against what the device has free: beyond 70 %
+        // codes of the whole matrix (1 B per cell) against what the device has free: beyond 70 %
         // of it -- or when PSA_BAND_ROWS asks for it -- align in linear space
         size_t free_b = 0, total_b = 0;
-        const double code_bytes = 0.75 * (double)n * (double)m;
+        const double code_bytes = (double)n * (double)m;
         const bool forced = getenv("PSA_BAND_ROWS") != nullptr;
         if (forced || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && code_bytes > 0.7 * (double)free_b))
             return psa_align_banded(a, n, b, m, 0, score_out, ai_out, bj_out, len_out);
@@ -648,8 +664,7 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
         if (r0 > 0 && i - (k != 2) <= r0) continue;            // the walk left this band without a step in it
         const int Wr = (int)std::min<int64_t>(s->W, j);
         const int Qr = (Wr + 63 + 63) / 64;
-        uint32_t* base = (uint32_t*)((uintptr_t)s->codes -
-                                     sizeof(uint32_t) * (uintptr_t)psa::code_word_index(r0 / 64, Qr, 0, 0, 0, 0));
+        uint8_t* base = (uint8_t*)((uintptr_t)s->codes - (uintptr_t)psa::code_tile_offset(r0 / 64, Qr, 0));
         if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "banded: band %lld rows %lld..%lld columns %d, walk at (%lld,%lld,%d)\n", (long long)bnd, (long long)r0, (long long)r1, Wr, (long long)i, (long long)j, k);
         FillOpts fo;
         fo.codes = 1; fo.W = Wr; fo.codes_base = base; fo.any_order = true;
