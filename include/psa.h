@@ -36,7 +36,7 @@ extern "C" {
 #define PSA_E_KERNEL (-5)     /* a kernel reported a stalled hand-off (bounded spin expired) */
 #define PSA_E_STATE (-6)      /* calls made in the wrong order */
 
-#define PSA_F_TRACEBACK 1u    /* keep packed winner codes in HBM so an alignment can be rebuilt */
+#define PSA_F_TRACEBACK 1u    /* keep winner codes in HBM (one byte per cell) so an alignment can be rebuilt */
 #define PSA_F_BANDED 2u       /* with PSA_F_TRACEBACK: codes for one band of rows at a time (psa_align_banded) */
 
 const char* psa_last_error(void);
@@ -55,6 +55,11 @@ void psa_free(void* p);
  * reference the result does not depend on p.  p < 1 is an error (the reference divides by
  * zero, simple.cpp:92).
  * Outputs: *score_out = result.score; (*ai_out, *bj_out, *len_out) = result.al.data.
+ * On one GPU all p stripes are jobs of ONE kernel launch: stripe g+1 takes the rows of its left
+ * boundary as stripe g's strips finish them (the mailbox of simple.cpp:136-154 as flags in device
+ * memory), so p costs a few per cent, not a factor.  The stripe objects of the calling thread's most
+ * recent whole-pair call are kept and reused by the next call of the same shape (n, m, p):
+ * psa_release_cache() frees them.
  */
 int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
               int32_t* score_out, int32_t** ai_out, int32_t** bj_out, int64_t* len_out);
@@ -63,6 +68,54 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
  * traceback storage.  triple_out (may be NULL) receives T1,T2,T3 at (n, m). */
 int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
               int32_t* score_out, int32_t triple_out[3]);
+
+/* Free the device buffers psa_align / psa_score keep for the calling thread (see psa_align). */
+void psa_release_cache(void);
+
+/* ---- several pairs at once: run() called in a loop (simple.cpp:311), one launch per batch ------
+ *
+ * One 2^16 pair cannot fill the GPU (its dependency chain is n + m anti-diagonal steps long whatever
+ * the hardware), so throughput comes from pairs in flight.  psa_align_many aligns npairs independent
+ * pairs: a[k] (n[k] bytes) against b[k] (m[k] bytes); scores_out[k] = result.score, and -- when
+ * ai_out, bj_out, len_out are not NULL -- (ai_out[k], bj_out[k], len_out[k]) = result.al.data of pair
+ * k, each array released with psa_free().  Results are those of psa_align pair by pair.  Internally
+ * two psa_many engines take turns: every batch is ONE fill launch over all its pairs (the strips of
+ * the pairs interleaved, each pair advancing at the pace of its own chain) and ONE launch of their
+ * traceback walks, which run beside the next batch's fill.  One host thread, two streams.
+ */
+int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, const uint8_t* const* b,
+                   const int64_t* m, int32_t* scores_out, int32_t** ai_out, int32_t** bj_out,
+                   int64_t* len_out);
+
+/* The engine behind it, for callers whose pairs are resident in device memory or who run their own
+ * loop.  `slots` (1..8) pairs of up to n_cap x m_cap are in flight per launch; flags: PSA_F_TRACEBACK
+ * for alignments, 0 for scores.  All device and pinned host buffers are allocated by create; the
+ * other calls allocate nothing on the device (a changed set of pair sizes re-uploads a few KB of
+ * ticket order).  An engine owns a stream; calls on one engine must not overlap, engines are independent.
+ *   set_pair / set_pair_dev  bind a slot to a pair (host / device residues; copies and the encoding
+ *                            kernels are queued on the engine's stream); clear_slot leaves it out
+ *   launch                   queue ONE fill launch over all bound slots, ONE launch of their walks and
+ *                            the copies of the results to pinned host memory; returns at once
+ *   wait                     block until those results are on the host
+ *   result                   score (and T1,T2,T3 at (n, m) when triple_out is not NULL) of a slot; with
+ *                            ai/bj (capacity cap >= 2 (n + m) + 2 each) also the finished alignment,
+ *                            prefix fix-up of simple.cpp:279-290 applied
+ *   last_ms                  device time of the last launch's fill and of its walks (HIP events on
+ *                            the engine's stream)
+ */
+typedef struct psa_many psa_many;
+int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uint32_t flags);
+void psa_many_destroy(psa_many* e);
+int psa_many_set_pair(psa_many* e, int slot, const uint8_t* a, int64_t n, const uint8_t* b, int64_t m);
+int psa_many_set_pair_dev(psa_many* e, int slot, const uint8_t* a_dev, int64_t n, const uint8_t* b_dev,
+                          int64_t m);
+int psa_many_clear_slot(psa_many* e, int slot);
+int psa_many_launch(psa_many* e);
+int psa_many_wait(psa_many* e);
+int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_out[3], int32_t* ai,
+                    int32_t* bj, int64_t cap, int64_t* len_out);
+int psa_many_last_ms(psa_many* e, float* fill_ms_out, float* walk_ms_out);
+int64_t psa_many_code_bytes(const psa_many* e, int slot);
 
 /*
  * Many independent pairs, score only, one GPU, no communication (BASELINE config 5).
@@ -76,8 +129,9 @@ int psa_score_batch(const uint8_t* seqs, const int64_t* offsets, int64_t nseqs,
 /* Same with everything RESIDENT in device memory (the form a serving loop and bench use):
  * seqs_dev/offsets_dev/pairs_dev as above, scores_dev receives npairs int32, counter_dev is a
  * 256-byte device scratch the library zeroes (its work counter).  max_len_b = the longest second
- * sequence among the pairs (sizes the per-wavefront LDS row buffer), at most 1024: longer pairs
- * go through psa_score.  Asynchronous on `stream`. */
+ * sequence among the pairs (sizes the per-wavefront LDS row buffer), at most 1024: a pair whose
+ * second sequence is longer is NOT aligned, its score slot receives INT32_MIN, and the caller
+ * sends it through psa_score (psa_score_batch does).  Asynchronous on `stream`. */
 int psa_score_batch_dev(const uint8_t* seqs_dev, const int64_t* offsets_dev, const int32_t* pairs_dev,
                         int64_t npairs, int max_len_b, int32_t* scores_dev, unsigned* counter_dev,
                         void* stream);
@@ -151,10 +205,10 @@ int64_t psa_stripe_code_bytes(const psa_stripe* s);
 
 /* run() in linear space (the idea complex.cpp:193-689 attempts): same result as
  * psa_align, but the winner codes of only `band_rows` rows (rounded up to a multiple of 256; 0 = chosen so that
- * they take about 8 GB) exist at any time.  Pass 1 fills score-only (one launch) and keeps the row
+ * they take about 8 GB, less when less is free) exist at any time.  Pass 1 fills score-only (one launch) and keeps the row
  * in front of every band (8 bytes per column and band); pass 2 goes through the bands bottom-up,
  * refills one band with codes -- only the columns left of where the walk enters it -- and walks it.
- * About twice the work of psa_align, for pairs whose codes (0.75 byte per cell) do not fit in HBM.
+ * About twice the work of psa_align, for pairs whose codes (one byte per cell) do not fit in HBM.
  * psa_align switches to it by itself when they do not, or when PSA_BAND_ROWS is set. */
 int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int64_t band_rows,
                      int32_t* score_out, int32_t** ai_out, int32_t** bj_out, int64_t* len_out);

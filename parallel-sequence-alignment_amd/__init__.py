@@ -9,10 +9,12 @@ The directory name contains a hyphen, so import it through the ``psa_amd`` shim 
 root (``import psa_amd``) or with ``importlib.import_module("parallel-sequence-alignment_amd")``.
 """
 from .binding import (  # noqa: F401
+    Many,
     PsaError,
     Result,
     Stripe,
     align,
+    align_many,
     device_count,
     finish_alignment,
     format_result,
@@ -21,6 +23,7 @@ from .binding import (  # noqa: F401
     pick,
     read_fasta,
     read_fasta_records,
+    release_cache,
     run,
     score,
     score_batch,

@@ -55,6 +55,19 @@ _SIGNATURES = {
     "psa_read_fasta": (C.c_void_p, [C.c_char_p, _i64p]),
     "psa_read_fasta_records": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i64p]),
     "psa_synth_protein": (None, [C.c_uint64, _i64, C.c_void_p]),
+    "psa_release_cache": (None, []),
+    "psa_align_many": (C.c_int, [_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "psa_many_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _i64, _i64, C.c_uint32]),
+    "psa_many_destroy": (None, [C.c_void_p]),
+    "psa_many_set_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
+    "psa_many_set_pair_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
+    "psa_many_clear_slot": (C.c_int, [C.c_void_p, C.c_int]),
+    "psa_many_launch": (C.c_int, [C.c_void_p]),
+    "psa_many_wait": (C.c_int, [C.c_void_p]),
+    "psa_many_result": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, C.c_void_p, C.c_void_p, _i64, _i64p]),
+    "psa_many_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "psa_many_code_bytes": (_i64, [C.c_void_p, C.c_int]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))
@@ -212,6 +225,91 @@ def synth_protein(seed, n):
     out = np.zeros(int(n), np.uint8)
     lib().psa_synth_protein(C.c_uint64(seed), int(n), _ptr(out))
     return out
+
+
+def release_cache():
+    lib().psa_release_cache()
+
+
+def align_many(pairs, alignments=True):
+    """run() for every (a, b) of `pairs` (psa_align_many): a list of Result; ai/bj are empty when alignments is False."""
+    seqs = [(_seq(a), _seq(b)) for a, b in pairs]
+    k = len(seqs)
+    pa = (C.c_void_p * k)(*[x[0].ctypes.data if x[0].size else None for x in seqs])
+    pb = (C.c_void_p * k)(*[x[1].ctypes.data if x[1].size else None for x in seqs])
+    na = (_i64 * k)(*[x[0].size for x in seqs])
+    nb = (_i64 * k)(*[x[1].size for x in seqs])
+    scores = (_i32 * k)()
+    if alignments:
+        ai, bj, ln = (C.c_void_p * k)(), (C.c_void_p * k)(), (_i64 * k)()
+        _check(lib().psa_align_many(k, pa, na, pb, nb, scores, ai, bj, ln))
+    else:
+        _check(lib().psa_align_many(k, pa, na, pb, nb, scores, None, None, None))
+    out = []
+    for i in range(k):
+        if alignments and ln[i]:
+            xa = np.ctypeslib.as_array(C.cast(ai[i], _i32p), shape=(ln[i],)).copy()
+            xb = np.ctypeslib.as_array(C.cast(bj[i], _i32p), shape=(ln[i],)).copy()
+        else:
+            xa, xb = np.zeros(0, np.int32), np.zeros(0, np.int32)
+        if alignments:
+            lib().psa_free(ai[i])
+            lib().psa_free(bj[i])
+        out.append(Result(scores[i], xa, xb))
+    return out
+
+
+class Many:
+    """psa_many engine: up to `slots` pairs filled by ONE launch and walked by ONE launch."""
+
+    def __init__(self, slots, n_cap, m_cap, traceback=True):
+        self._h = C.c_void_p()
+        self.slots, self.n_cap, self.m_cap, self.traceback = slots, int(n_cap), int(m_cap), traceback
+        _check(lib().psa_many_create(C.byref(self._h), slots, self.n_cap, self.m_cap, PSA_F_TRACEBACK if traceback else 0))
+        self._keep = {}
+
+    def close(self):
+        if self._h:
+            lib().psa_many_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def set_pair(self, slot, a, b):
+        a, b = _seq(a), _seq(b)
+        self._keep[slot] = (a, b)
+        _check(lib().psa_many_set_pair(self._h, slot, _ptr(a), a.size, _ptr(b), b.size))
+
+    def set_pair_dev(self, slot, a_ptr, n, b_ptr, m):
+        _check(lib().psa_many_set_pair_dev(self._h, slot, a_ptr, int(n), b_ptr, int(m)))
+
+    def clear_slot(self, slot):
+        _check(lib().psa_many_clear_slot(self._h, slot))
+
+    def launch(self):
+        _check(lib().psa_many_launch(self._h))
+
+    def wait(self):
+        _check(lib().psa_many_wait(self._h))
+
+    def result(self, slot, n, m, want_alignment=True):
+        """Result of a slot after launch(): (score, ai, bj), waiting for the launch if need be."""
+        sc = _i32()
+        if not (want_alignment and self.traceback):
+            _check(lib().psa_many_result(self._h, slot, C.byref(sc), None, None, None, 0, None))
+            return Result(sc.value, np.zeros(0, np.int32), np.zeros(0, np.int32))
+        cap = 2 * (int(n) + int(m)) + 2
+        ai, bj, ln = np.zeros(cap, np.int32), np.zeros(cap, np.int32), _i64()
+        _check(lib().psa_many_result(self._h, slot, C.byref(sc), None, _ptr(ai), _ptr(bj), cap, C.byref(ln)))
+        return Result(sc.value, ai[:ln.value].copy(), bj[:ln.value].copy())
+
+    def last_ms(self):
+        f, w = C.c_float(), C.c_float()
+        _check(lib().psa_many_last_ms(self._h, C.byref(f), C.byref(w)))
+        return f.value, w.value
+
+    def code_bytes(self, slot):
+        return lib().psa_many_code_bytes(self._h, slot)
 
 
 class Stripe:

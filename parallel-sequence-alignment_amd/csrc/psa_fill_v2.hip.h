@@ -36,10 +36,12 @@ namespace psa {
 // HBM-fed strip 8 % slower than the LDS-fed ones, and the slowest strip sets the pace of its chain.
 constexpr int kGranCols = PSA_GRAN_COLS;
 constexpr int kGDist = PSA_GDIST;  // granule requests run this many blocks ahead (1, 2 or 4)
-#ifndef PSA_KEEPOUT_WORDS
-#define PSA_KEEPOUT_WORDS (24 * 1024)
-#endif
-constexpr int kKeepoutWords = PSA_KEEPOUT_WORDS;   // 96 KB of LDS kept out of use, see fill_strips_v2
+// Dynamic LDS a fill workgroup is launched with and never uses (see fill_strips_v2).  One pair alone: 96 KB, so that
+// neither a second fill workgroup nor a traceback walk (70 KB) fits on the CU beside it.  Several pairs in one
+// launch: 70 KB -- still no second fill workgroup (2 x 82 KB > 160 KB), but the walks of the previous batch
+// find room beside the fill of the next one (82 + 70 KB).
+constexpr int kKeepoutAloneBytes = 96 * 1024;
+constexpr int kKeepoutManyBytes = 70 * 1024;
 constexpr int kFrontWord = 32;  // control block: [0] ticket, [1] abort flag, [32] front (own cache line)
 constexpr int kNW = 4;         // strips (wavefronts) per workgroup
 constexpr int kRing = 256;     // LDS ring slots per strip boundary (8 bytes each)
@@ -53,6 +55,22 @@ struct FillArgs2 {
     const uint32_t* eqtab;    // [kMaxSym][tab_pitch] words, byte c%4 of word kTabPad + c/4 = score(sym, B[c]): a byte, so that
                               // the step adds it with an SDWA byte select and needs no extract
     int tab_pitch;
+};
+
+// One launch can fill several stripes at once -- of different pairs, or the column stripes of one pair.
+// The workgroups draw tickets from one counter and order[ticket] names (job, group of 4 strips).  The host
+// lays the order out so that every job advances at the pace of its own dependency chain (independent
+// pairs: round-robin; stripes of one pair: stripe g+1 trails stripe g by the time a strip takes) and
+// together they keep every CU busy, which one 2^16 pair alone cannot (its chain is n + m steps long
+// whatever the hardware).  A workgroup only ever waits for workgroups with lower tickets, which run
+// already or have finished: no assumption on dispatch order or residency.
+constexpr int kMaxJobs = 8;
+constexpr int kOrderJobShift = 24;   // order[t] = job << 24 | group
+struct FillBatch {
+    FillArgs2 job[kMaxJobs];
+    int njobs;
+    const uint32_t* order;        // null: one job, group = ticket
+    unsigned* ticket;             // launch-wide ticket counter, zeroed before the launch
 };
 
 // ---- alphabet + table construction (FASTA-to-device encoding) ----
@@ -530,24 +548,29 @@ template <bool CODES>
 // One workgroup per CU, one wavefront per SIMD: every strip is a link of one dependency chain, so
 // two workgroups sharing a CU (each at half speed) would hold up every strip behind them.  The
 // occupancy attribute makes the register budget 512 per wave and keeps a second workgroup out.
-__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WAVES_PER_EU, PSA_WAVES_PER_EU))) void fill_strips_v2(FillArgs2 q) {
+__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WAVES_PER_EU, PSA_WAVES_PER_EU))) void fill_strips_v2(FillBatch B) {
     __shared__ FillLds lds;
     __shared__ unsigned wg_ticket;
-    // LDS nobody uses: with it a workgroup takes more than half of a CU's 160 KB, so that no second
-    // fill workgroup and no traceback walk (64 KB) can be placed beside it.  Every strip is a link
+    // Dynamic LDS nobody uses (its size is chosen at the launch): with it a workgroup takes more than half
+    // of a CU's 160 KB, so that no second fill workgroup can be placed beside it.  Every strip is a link
     // of one dependency chain: a wave that shares its SIMD's issue slots holds up the whole chain.
-    __shared__ unsigned lds_keepout[kKeepoutWords];
-    if (q.base.W < 0) { lds_keepout[threadIdx.x] = q.base.Q; __syncthreads(); q.base.ticket[2] = lds_keepout[threadIdx.x ^ 1]; }   // (never true; keeps the array allocated)
-    const FillArgs& p = q.base;
+    extern __shared__ unsigned lds_keepout[];
     StripCtx<CODES> c;
     const int lane = c.lane = threadIdx.x & 63;
     const int wv = c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) wg_ticket = atomicAdd(p.ticket, 1u);
+    if (threadIdx.x == 0) wg_ticket = atomicAdd(B.ticket, 1u);
     if (threadIdx.x < kNW) { lds.prod[threadIdx.x] = 0; lds.cons[threadIdx.x] = 0; }
     __syncthreads();
+    // ticket -> (job, group)
+    const unsigned tk = __builtin_amdgcn_readfirstlane(wg_ticket);
+    const unsigned og = B.order ? __builtin_amdgcn_readfirstlane(B.order[tk]) : tk;
+    const unsigned group = og & ((1u << kOrderJobShift) - 1);
+    const FillArgs2 q = B.job[og >> kOrderJobShift];   // (a copy: loaded once, kept in SGPRs)
+    const FillArgs& p = q.base;
+    if (p.W < 0) lds_keepout[threadIdx.x] = group;   // (never true; keeps the dynamic LDS referenced)
     const int64_t R = c.R = p.r1 - p.r0;
     const int64_t strips = (R + 63) >> 6;
-    const int64_t s = (int64_t)__builtin_amdgcn_readfirstlane(wg_ticket) * kNW + wv;  // strip inside the chunk
+    const int64_t s = (int64_t)group * kNW + wv;  // strip inside the chunk
     if (s >= strips) return;
 #ifdef PSA_FILL_STATS   // experiment: time a workgroup sits on its CU before / while it works (control block words 48..)
     const unsigned long long st_entry = wall_clock64();
@@ -569,10 +592,31 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     if (p.left) {
         const int64_t y = i - p.r0 - 1;
         const int64_t yo = row_ok ? y : (R - 1);
-        o1 = p.left[yo]; o2 = p.left[R + yo]; o3 = p.left[2 * R + yo];
-        if (yo >= 1) { u1 = p.left[yo - 1]; u2 = p.left[R + yo - 1]; u3 = p.left[2 * R + yo - 1]; }
-        else if (p.r0 > 0) { u1 = p.corner[0]; u2 = p.corner[1]; u3 = p.corner[2]; }
-        else boundary_triple(0, c0, u1, u2, u3);
+        if (p.left_done) {
+            // the stripe on the left is filled by this same launch: wait until it has stored this strip's rows
+            // (and the row above them), then read them past this CU's cache (agent scope), as it stored them
+            Spin spins;
+            for (;;) {
+                const unsigned f1 = __hip_atomic_load(p.left_done + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned f0 = sg > 0 ? __hip_atomic_load(p.left_done + sg - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+                if (__builtin_amdgcn_readfirstlane(f1 & f0)) break;
+                if (spin_expired(spins, p.abort_flag)) return;
+                __builtin_amdgcn_s_sleep(32);
+            }
+            o1 = __hip_atomic_load(p.left + yo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            o2 = __hip_atomic_load(p.left + R + yo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            o3 = __hip_atomic_load(p.left + 2 * R + yo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (yo >= 1) {
+                u1 = __hip_atomic_load(p.left + yo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u2 = __hip_atomic_load(p.left + R + yo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u3 = __hip_atomic_load(p.left + 2 * R + yo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else boundary_triple(0, c0, u1, u2, u3);   // (one launch covers all rows: r0 == 0)
+        } else {
+            o1 = p.left[yo]; o2 = p.left[R + yo]; o3 = p.left[2 * R + yo];
+            if (yo >= 1) { u1 = p.left[yo - 1]; u2 = p.left[R + yo - 1]; u3 = p.left[2 * R + yo - 1]; }
+            else if (p.r0 > 0) { u1 = p.corner[0]; u2 = p.corner[1]; u3 = p.corner[2]; }
+            else boundary_triple(0, c0, u1, u2, u3);
+        }
     } else {
         boundary_triple(i, 0, o1, o2, o3);
         boundary_triple(i - 1, 0, u1, u2, u3);
@@ -632,7 +676,7 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     // the distance to the front, so a workgroup looks a handful of times in all.  Once the
     // workgroup two above has begun, this one's input is some tens of microseconds away and it
     // goes on to poll its own granules finely.
-    c.wg = __builtin_amdgcn_readfirstlane(wg_ticket);
+    c.wg = (int)group;
     if (wv == 0 && c.wg >= 2 && W >= 128) {
         Spin spins;
         for (;;) {
@@ -686,12 +730,20 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
     // right boundary / final triple, captured when each lane passed column W-1
     if (row_ok) {
         const int bias = (int)(3 * (i + c0 + W));
-        if (p.right) {
+        if (p.right && p.right_done) {   // read by the next stripe inside this launch: write through
+            __hip_atomic_store(p.right + c.y_row, c.S.r1 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.right + R + c.y_row, c.S.r2 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.right + 2 * R + c.y_row, c.S.r3 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (p.right) {
             p.right[c.y_row] = c.S.r1 - bias; p.right[R + c.y_row] = c.S.r2 - bias; p.right[2 * R + c.y_row] = c.S.r3 - bias;
         }
         if (i == p.n) {
             p.final_triple[0] = c.S.r1 - bias; p.final_triple[1] = c.S.r2 - bias; p.final_triple[2] = c.S.r3 - bias;
         }
+    }
+    if (p.right_done) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left before the flag does
+        if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
 #ifdef PSA_FILL_STATS

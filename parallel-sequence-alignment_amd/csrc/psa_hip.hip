@@ -55,39 +55,58 @@ int pick3(const int32_t t[3], int32_t* v) {
     return 3;
 }
 
-// control block: bytes 0..255 are per launch (ticket, front, statistics), bytes 256..511 per pass (the abort
-// flag: a hand-off wait that expired in ANY chunk of the pass stays visible until the pass is over)
 constexpr size_t kSeqPad = 64;
+// Control blocks of a stripe: kCtrlRing blocks of 256 bytes, one per launch in flight (word 0 the ticket
+// counter, word 32 the chain front, words 48.. statistics), and one block per PASS (word 0: the abort
+// flag -- a hand-off wait that expired in ANY chunk of the pass stays visible until the pass is over).
+constexpr int kCtrlRing = 4;
 constexpr size_t kCtrlLaunchBytes = 256;
-constexpr size_t kCtrlBytes = 512;
-constexpr int kAbortWord = 64;
+constexpr size_t kCtrlBytes = (kCtrlRing + 1) * kCtrlLaunchBytes;
+constexpr int kAbortWord = kCtrlRing * 64;
+constexpr int kCornerSlots = 4;                 // triples at (r0, c0) of the chunks in flight
+constexpr int kFinalWord = 4 * kCornerSlots;    // the final triple lives behind them in `small`
+constexpr size_t kAlphaBytes = 256 * 4 + 16 + 256 + 32;
 
-// rows per band in banded mode: PSA_BAND_ROWS, else as many strips as 8 GiB of codes hold
+// The current HIP device is a per-thread setting.  Every call that works on an object makes the object's
+// device current for its own duration and puts the caller's back on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int rc = PSA_OK;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) { rc = fail(PSA_E_HIP, "hipGetDevice failed"); return; }
+        if (prev != dev) {
+            if (hipSetDevice(dev) != hipSuccess) { rc = fail(PSA_E_HIP, "hipSetDevice(%d) failed", dev); return; }
+            switched = true;
+        }
+    }
+    ~DeviceGuard() { if (switched) hipSetDevice(prev); }
+};
+
 thread_local int64_t g_band_rows_request = 0;   // set by psa_align_banded around the stripe's creation
-int64_t band_rows_for(int64_t n, int Q) {
-    int64_t want = g_band_rows_request;
-    if (want <= 0) if (const char* e = getenv("PSA_BAND_ROWS")) want = atoll(e);
-    if (want <= 0) want = 64 * std::max<int64_t>(1, (8LL << 30) / ((int64_t)Q * psa::kTileBytes));
-    const int64_t wg_rows = 64 * psa::kNW;   // band boundaries coincide with workgroup boundaries
-    want = std::max<int64_t>(wg_rows, ((want + wg_rows - 1) / wg_rows) * wg_rows);
-    return std::min<int64_t>(want, ((n + wg_rows - 1) / wg_rows) * wg_rows);
-}
 
 }  // namespace
 
 struct psa_stripe {
-    int64_t n = 0, m = 0, c0 = 0, c1 = 0;
-    int W = 0, Q = 0, Wpad = 0;
+    int device = 0;              // the HIP device the stripe lives on (current when it was created)
     uint32_t flags = 0;
+    // ---- capacity: what the device buffers were sized for ----
+    int64_t n_cap = 0;
+    int W_cap = 0, Wpad_cap = 0, pitch_cap = 0;
+    size_t code_cap = 0;
+    // ---- binding: the pair (and columns of it) the stripe currently holds ----
+    int64_t n = 0, m = 0, c0 = 0, c1 = 0;
+    int W = 0, Q = 0, Wpad = 0, tab_pitch = 0;
+    size_t code_bytes = 0;
     uint8_t* a_dev = nullptr;
     uint8_t* b_dev = nullptr;    // = b_alloc + kSeqPad: the traceback's residue windows start up to 64 bytes in front
     uint8_t* b_alloc = nullptr;
     psa::u64* ring = nullptr;
     uint8_t* codes = nullptr;    // winner codes, one byte per cell in 4 KB tiles (psa_device.hip.h)
     int2* leftcol = nullptr;     // c0 > 0: (D, H') of column c0 per row, kept for the traceback
-    size_t code_bytes = 0;
-    int32_t* small = nullptr;    // corner A[3] (pad 4), corner B[3] (pad 4), final[3] (pad 4)
-    unsigned* ctrl = nullptr;    // [0] ticket, [32] front, [64] abort flag (kCtrlBytes)
+    int32_t* small = nullptr;    // kCornerSlots corner triples (pad 4), final[3] (pad 4)
+    unsigned* ctrl = nullptr;    // kCtrlBytes, see above
+    unsigned* done = nullptr;    // per strip: this stripe's right boundary rows are stored (stripes filled by one launch)
     int32_t* tb_ai = nullptr;
     int32_t* tb_bj = nullptr;
     int64_t tb_cap = 0;
@@ -95,11 +114,11 @@ struct psa_stripe {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t next_r0 = 0;
     int corner_cur = 0;
+    unsigned launch_no = 0;
     // v2 kernel: symbol ids of A and the per-symbol substitution table of this stripe's B
     uint8_t* a_ids = nullptr;
     uint8_t* alpha = nullptr;    // present[256] (u32) | meta[4] (u32) | map[256] | inv[32]
     uint32_t* eqtab = nullptr;
-    int tab_pitch = 0;
     unsigned nsym = 0;
     bool use_v2 = false;
     bool fill_timed = false, tb_timed = false;
@@ -107,36 +126,114 @@ struct psa_stripe {
     // was before each band (see align_banded)
     int64_t band_rows = 0;
     psa::u64* ckpt = nullptr;
-    int device = 0;              // the HIP device the stripe lives on (current when it was created)
 };
 
 namespace {
-// The current HIP device is a per-thread setting and a new host thread starts on device 0: every call
-// that works on a stripe first makes the stripe's own device current (callers keep one thread per
-// alignment in flight, bench.py for one).
-int enter_device(const psa_stripe* s) {
-    int cur = -1;
-    HIP_TRY(hipGetDevice(&cur));
-    if (cur != s->device) HIP_TRY(hipSetDevice(s->device));
+
+int tab_pitch_for(int Q) { return psa::kTabPad + (64 * Q + 64) / 4 + 40; }   // a byte per column; the last superblock requests 32 words ahead
+int steps_q(int W) { return (W + 63 + 63) / 64; }
+
+// rows per band in banded mode: the request (argument or PSA_BAND_ROWS), else as many strips as 8 GiB --
+// or, when less is free, a third of the free device memory -- of codes hold
+int64_t band_rows_for(int64_t n, int Q) {
+    int64_t want = g_band_rows_request;
+    if (want <= 0) if (const char* e = getenv("PSA_BAND_ROWS")) want = atoll(e);
+    if (want <= 0) {
+        size_t free_b = 0, total_b = 0;
+        int64_t budget = 8LL << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<int64_t>(budget, (int64_t)(free_b / 3));
+        want = 64 * std::max<int64_t>(1, budget / ((int64_t)Q * psa::kTileBytes));
+    }
+    const int64_t wg_rows = 64 * psa::kNW;   // band boundaries coincide with workgroup boundaries
+    want = std::max<int64_t>(wg_rows, ((want + wg_rows - 1) / wg_rows) * wg_rows);
+    return std::min<int64_t>(want, ((n + wg_rows - 1) / wg_rows) * wg_rows);
+}
+
+void free_stripe(psa_stripe* s) {
+    if (!s) return;
+    DeviceGuard g(s->device);
+    hipFree(s->a_dev); hipFree(s->b_alloc); hipFree(s->ring); hipFree(s->codes); hipFree(s->leftcol);
+    hipFree(s->a_ids); hipFree(s->alpha); hipFree(s->eqtab);
+    hipFree(s->ckpt); hipFree(s->done);
+    hipFree(s->small); hipFree(s->ctrl); hipFree(s->tb_ai); hipFree(s->tb_bj); hipFree(s->tb_state);
+    for (auto& e : s->ev) if (e) hipEventDestroy(e);
+    delete s;
+}
+
+// Device buffers for any stripe of up to n_cap rows and W_cap columns (banded: sized for exactly this pair).
+int alloc_stripe(psa_stripe** out, int64_t n_cap, int W_cap, uint32_t flags, bool with_leftcol) {
+    psa_stripe* s = new psa_stripe();
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
+    s->flags = flags;
+    s->n_cap = n_cap; s->W_cap = W_cap;
+    s->Wpad_cap = ((W_cap + 63) / 64) * 64;
+    const int Q_cap = steps_q(W_cap);
+    s->pitch_cap = tab_pitch_for(Q_cap);
+    const int64_t strips = (n_cap + 63) / 64;
+#define CREATE_TRY(expr)                                                          \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            free_stripe(s);                                                       \
+            return fail(e_ == hipErrorOutOfMemory ? PSA_E_NOMEM : PSA_E_HIP,      \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));           \
+        }                                                                         \
+    } while (0)
+    // (both padded: the traceback fetches whole 64-row / 128-column residue windows beside each code tile)
+    CREATE_TRY(hipMalloc(&s->a_dev, (size_t)n_cap + 2 * kSeqPad));
+    CREATE_TRY(hipMalloc(&s->b_alloc, (size_t)W_cap + 4 * kSeqPad));
+    s->b_dev = s->b_alloc + kSeqPad;
+    CREATE_TRY(hipMalloc(&s->ring, sizeof(psa::u64) * (2 * (size_t)s->Wpad_cap + 64)));  // + dump slots, see fill_strips_v2
+    CREATE_TRY(hipMalloc(&s->small, 256));
+    CREATE_TRY(hipMalloc(&s->ctrl, kCtrlBytes));
+    CREATE_TRY(hipMalloc(&s->done, sizeof(unsigned) * (size_t)(strips + 64)));
+    if (flags & PSA_F_TRACEBACK) {
+        int64_t code_strips = strips;
+        if (flags & PSA_F_BANDED) {
+            s->band_rows = band_rows_for(n_cap, Q_cap);
+            code_strips = s->band_rows / 64;
+            const int64_t nbands = (n_cap + s->band_rows - 1) / s->band_rows;
+            CREATE_TRY(hipMalloc(&s->ckpt, sizeof(psa::u64) * (size_t)(nbands + 1) * (size_t)s->Wpad_cap));
+        }
+        s->code_cap = (size_t)code_strips * (size_t)Q_cap * psa::kTileBytes;
+        CREATE_TRY(hipMalloc(&s->codes, s->code_cap));
+        if (with_leftcol) CREATE_TRY(hipMalloc(&s->leftcol, sizeof(int2) * (size_t)(n_cap + 1)));
+        s->tb_cap = n_cap + W_cap + 2;
+        CREATE_TRY(hipMalloc(&s->tb_ai, sizeof(int32_t) * (size_t)s->tb_cap));
+        CREATE_TRY(hipMalloc(&s->tb_bj, sizeof(int32_t) * (size_t)s->tb_cap));
+        CREATE_TRY(hipMalloc(&s->tb_state, sizeof(int64_t) * 16));
+    }
+    for (auto& e : s->ev) CREATE_TRY(hipEventCreate(&e));
+    CREATE_TRY(hipMalloc(&s->a_ids, (size_t)n_cap + 64));
+    CREATE_TRY(hipMalloc(&s->alpha, kAlphaBytes));
+    CREATE_TRY(hipMalloc(&s->eqtab, sizeof(uint32_t) * (size_t)psa::kMaxSym * (size_t)s->pitch_cap));
+    CREATE_TRY(hipMemset(s->ctrl, 0, kCtrlBytes));
+#undef CREATE_TRY
+    *out = s;
     return PSA_OK;
 }
-// what one fill launch may override (banded mode)
-struct FillOpts {
-    int codes = -1;                  // -1: as the stripe was created; 0 / 1: without / with winner codes
-    int W = 0;                       // > 0: only the stripe's first W columns
-    uint8_t* codes_base = nullptr;   // where strip 0's codes would lie
-    bool any_order = false;          // do not insist on r0 == end of the previous chunk
-};
-int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev, void* stream,
-                   const FillOpts& o);
-}  // namespace
 
-namespace {
+// Point the stripe at columns (c0, c1] of an n x m pair (within its capacity).
+int bind_stripe(psa_stripe* s, int64_t n, int64_t m, int64_t c0, int64_t c1) {
+    const int W = (int)(c1 - c0);
+    if (n < 1 || n > s->n_cap || W < 1 || W > s->W_cap || c0 < 0 || c1 > m)
+        return fail(PSA_E_ARG, "stripe of %lld rows x %d columns does not fit its buffers (%lld x %d)", (long long)n, W,
+                    (long long)s->n_cap, s->W_cap);
+    if (c0 > 0 && (s->flags & PSA_F_TRACEBACK) && !s->leftcol) return fail(PSA_E_STATE, "stripe was allocated without a left boundary column");
+    s->n = n; s->m = m; s->c0 = c0; s->c1 = c1;
+    s->W = W; s->Q = steps_q(W); s->Wpad = ((W + 63) / 64) * 64; s->tab_pitch = tab_pitch_for(s->Q);
+    if (s->flags & PSA_F_TRACEBACK) {
+        const int64_t strips = (n + 63) / 64;
+        s->code_bytes = (size_t)(s->band_rows ? s->band_rows / 64 : strips) * (size_t)s->Q * psa::kTileBytes;
+    }
+    s->next_r0 = 0; s->corner_cur = 0;
+    s->fill_timed = s->tb_timed = false;
+    return PSA_OK;
+}
 
-constexpr size_t kAlphaBytes = 256 * 4 + 16 + 256 + 32;
-
-// FASTA-to-device encoding for the v2 kernel: symbol ids of A, substitution table of B.
-int rebuild_tables(psa_stripe* s, hipStream_t st) {
+// FASTA-to-device encoding for the v2 kernel: symbol ids of A, substitution table of B.  nsym_known >= 0:
+// the caller has counted A's distinct residues itself (host sequences) and no device round trip is needed.
+int rebuild_tables(psa_stripe* s, hipStream_t st, int nsym_known) {
     unsigned* present = (unsigned*)s->alpha;
     unsigned* meta = present + 256;
     uint8_t* map = (uint8_t*)(meta + 4);
@@ -150,130 +247,44 @@ int rebuild_tables(psa_stripe* s, hipStream_t st) {
     hipLaunchKernelGGL(psa::build_eqtab, dim3((unsigned)((s->tab_pitch + 255) / 256), psa::kMaxSym), dim3(256), 0, st,
                        s->b_dev, s->W, meta, inv, s->eqtab, s->tab_pitch);
     HIP_TRY(hipGetLastError());
-    unsigned k = 0;
-    HIP_TRY(hipMemcpyAsync(&k, meta, sizeof k, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    unsigned k = (unsigned)nsym_known;
+    if (nsym_known < 0) {
+        HIP_TRY(hipMemcpyAsync(&k, meta, sizeof k, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     s->nsym = k;
     const char* force = getenv("PSA_FILL_KERNEL");
     s->use_v2 = k <= (unsigned)psa::kMaxSym && !(force && !strcmp(force, "v1"));
     return PSA_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-const char* psa_last_error(void) { return g_err.c_str(); }
-const char* psa_version(void) { return "psa-hip 0.1 (gfx950)"; }
-
-int psa_device_count(void) {
-    int cnt = 0;
-    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
-    return cnt;
+int count_symbols(const uint8_t* a, int64_t n) {
+    bool seen[256] = {false};
+    int k = 0;
+    for (int64_t i = 0; i < n; ++i) if (!seen[a[i]]) { seen[a[i]] = true; ++k; }
+    return k;
 }
 
-int psa_set_device(int device) {
-    if (int rc = need_device()) return rc;
-    HIP_TRY(hipSetDevice(device));
-    return PSA_OK;
+int upload_host(psa_stripe* s, const uint8_t* a, const uint8_t* b, hipStream_t st) {
+    HIP_TRY(hipMemcpyAsync(s->a_dev, a, (size_t)s->n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->b_dev, b + s->c0, (size_t)s->W, hipMemcpyHostToDevice, st));
+    return rebuild_tables(s, st, count_symbols(a, s->n));
 }
 
-void psa_free(void* p) { free(p); }
+// what one fill launch may override (banded mode)
+struct FillOpts {
+    int codes = -1;                  // -1: as the stripe was created; 0 / 1: without / with winner codes
+    int W = 0;                       // > 0: only the stripe's first W columns
+    uint8_t* codes_base = nullptr;   // where strip 0's codes would lie
+    bool any_order = false;          // do not insist on r0 == end of the previous chunk
+    const unsigned* left_done = nullptr;   // the stripe on the left is filled by the same launch (see FillArgs)
+    unsigned* right_done = nullptr;
+};
 
-void psa_stripe_destroy(psa_stripe* s) {
-    if (!s) return;
-    enter_device(s);
-    hipFree(s->a_dev); hipFree(s->b_alloc); hipFree(s->ring); hipFree(s->codes); hipFree(s->leftcol);
-    hipFree(s->a_ids); hipFree(s->alpha); hipFree(s->eqtab);
-    hipFree(s->ckpt);
-    hipFree(s->small); hipFree(s->ctrl); hipFree(s->tb_ai); hipFree(s->tb_bj); hipFree(s->tb_state);
-    for (auto& e : s->ev) if (e) hipEventDestroy(e);
-    delete s;
-}
-
-int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8_t* b, int64_t m,
-                      int64_t c0, int64_t c1, uint32_t flags) {
-    if (!out) return fail(PSA_E_ARG, "psa_stripe_create: out is null");
-    *out = nullptr;
-    if (n < 1 || m < 1 || c0 < 0 || c1 <= c0 || c1 > m || !a || !b)
-        return fail(PSA_E_ARG, "psa_stripe_create: need n>=1, m>=1, 0<=c0<c1<=m (n=%lld m=%lld c0=%lld c1=%lld)",
-                    (long long)n, (long long)m, (long long)c0, (long long)c1);
-    if (n > (1LL << 27) || m > (1LL << 27)) return fail(PSA_E_ARG, "sequence longer than 2^27 is not supported");
-    if (int rc = need_device()) return rc;
-    psa_stripe* s = new psa_stripe();
-    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
-    s->n = n; s->m = m; s->c0 = c0; s->c1 = c1; s->flags = flags;
-    s->W = (int)(c1 - c0);
-    s->Q = (s->W + 63 + 63) / 64;
-    s->Wpad = ((s->W + 63) / 64) * 64;
-    const int64_t strips = (n + 63) / 64;
-#define CREATE_TRY(expr)                                                          \
-    do {                                                                          \
-        hipError_t e_ = (expr);                                                   \
-        if (e_ != hipSuccess) {                                                   \
-            psa_stripe_destroy(s);                                                \
-            return fail(e_ == hipErrorOutOfMemory ? PSA_E_NOMEM : PSA_E_HIP,      \
-                        "%s failed: %s", #expr, hipGetErrorString(e_));           \
-        }                                                                         \
-    } while (0)
-    // (both padded: the traceback fetches whole 64-row / 128-column residue windows beside each code tile)
-    CREATE_TRY(hipMalloc(&s->a_dev, (size_t)n + 2 * kSeqPad));
-    CREATE_TRY(hipMalloc(&s->b_alloc, (size_t)s->W + 4 * kSeqPad));
-    s->b_dev = s->b_alloc + kSeqPad;
-    CREATE_TRY(hipMemcpy(s->a_dev, a, (size_t)n, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(s->b_dev, b + c0, (size_t)s->W, hipMemcpyHostToDevice));
-    CREATE_TRY(hipMalloc(&s->ring, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64)));  // + dump slots, see fill_strips_v2
-    CREATE_TRY(hipMalloc(&s->small, 64));
-    CREATE_TRY(hipMalloc(&s->ctrl, kCtrlBytes));
-    if (flags & PSA_F_TRACEBACK) {
-        int64_t code_strips = strips;
-        if (flags & PSA_F_BANDED) {
-            s->band_rows = band_rows_for(n, s->Q);
-            code_strips = s->band_rows / 64;
-            const int64_t nbands = (n + s->band_rows - 1) / s->band_rows;
-            CREATE_TRY(hipMalloc(&s->ckpt, sizeof(psa::u64) * (size_t)(nbands + 1) * (size_t)s->Wpad));
-        }
-        s->code_bytes = (size_t)code_strips * (size_t)s->Q * psa::kTileBytes;
-        CREATE_TRY(hipMalloc(&s->codes, s->code_bytes));
-        if (c0 > 0) CREATE_TRY(hipMalloc(&s->leftcol, sizeof(int2) * (size_t)(n + 1)));
-        s->tb_cap = n + s->W + 2;
-        CREATE_TRY(hipMalloc(&s->tb_ai, sizeof(int32_t) * (size_t)s->tb_cap));
-        CREATE_TRY(hipMalloc(&s->tb_bj, sizeof(int32_t) * (size_t)s->tb_cap));
-        CREATE_TRY(hipMalloc(&s->tb_state, sizeof(int64_t) * 12));
-    }
-    for (auto& e : s->ev) CREATE_TRY(hipEventCreate(&e));
-    s->tab_pitch = psa::kTabPad + (64 * s->Q + 64) / 4 + 40;   // a byte per column; the last superblock requests 32 words ahead
-    CREATE_TRY(hipMalloc(&s->a_ids, (size_t)n));
-    CREATE_TRY(hipMalloc(&s->alpha, kAlphaBytes));
-    CREATE_TRY(hipMalloc(&s->eqtab, sizeof(uint32_t) * (size_t)psa::kMaxSym * (size_t)s->tab_pitch));
-#undef CREATE_TRY
-    if (int rc = rebuild_tables(s, nullptr)) { psa_stripe_destroy(s); return rc; }
-    *out = s;
-    return PSA_OK;
-}
-
-int psa_stripe_set_sequences_dev(psa_stripe* s, const uint8_t* a_dev, const uint8_t* b_dev, void* stream) {
-    if (!s || !a_dev || !b_dev) return fail(PSA_E_ARG, "psa_stripe_set_sequences_dev: null argument");
-    if (int rc = enter_device(s)) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(s->a_dev, a_dev, (size_t)s->n, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->b_dev, b_dev, (size_t)s->W, hipMemcpyDeviceToDevice, st));
-    return rebuild_tables(s, st);
-}
-
-int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev,
-                         void* stream) {
-    if (s && s->band_rows) return fail(PSA_E_STATE, "psa_stripe_fill_rows: a banded stripe is driven by psa_align_banded");
-    return fill_rows_impl(s, r0, r1, left_dev, right_dev, stream, FillOpts());
-}
-
-}  // extern "C"
-
-namespace {
-int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev, void* stream,
-                   const FillOpts& o) {
-    if (!s) return fail(PSA_E_ARG, "psa_stripe_fill_rows: null stripe");
-    if (int rc = enter_device(s)) return rc;
+// Everything a fill of rows r0+1..r1 needs before its kernel can be launched (memsets on `st`), and the kernel
+// arguments.  Does not launch.
+int prepare_fill(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev, hipStream_t st,
+                 const FillOpts& o, psa::FillArgs2* out, bool* with_codes_out) {
     if (r0 == 0) s->next_r0 = 0;  // a new pass over the same stripe
     if (o.any_order) s->next_r0 = r0;
     if (r0 != s->next_r0) return fail(PSA_E_STATE, "psa_stripe_fill_rows: chunks out of order (r0=%lld, expected %lld)",
@@ -283,7 +294,6 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
                     (long long)r0, (long long)r1, (long long)s->n);
     if ((s->c0 == 0) != (left_dev == nullptr))
         return fail(PSA_E_ARG, "psa_stripe_fill_rows: left boundary must be given exactly when c0 > 0");
-    hipStream_t st = (hipStream_t)stream;
     if (r0 == 0 || o.any_order) {
         // A launch that does not continue the previous one must not find that one's granules: a granule
         // is recognised by its tag (strip number), and a strip that finds a left-over with the right tag
@@ -291,49 +301,87 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
         // (A banded refill takes its input from the checkpoint row, never from the ring.)
         HIP_TRY(hipMemsetAsync(s->ring, 0, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64), st));
         if (r0 == 0) s->corner_cur = 0;
-        HIP_TRY(hipMemsetAsync(s->ctrl + kAbortWord, 0, kCtrlBytes - kCtrlLaunchBytes, st));
+        HIP_TRY(hipMemsetAsync(s->ctrl + kAbortWord, 0, kCtrlLaunchBytes, st));
     }
-    HIP_TRY(hipMemsetAsync(s->ctrl, 0, kCtrlLaunchBytes, st));
+    // a control block of its own for every launch: the previous chunk's launch may still be running
+    unsigned* launch_ctrl = s->ctrl + (s->launch_no++ % kCtrlRing) * (kCtrlLaunchBytes / sizeof(unsigned));
+    HIP_TRY(hipMemsetAsync(launch_ctrl, 0, kCtrlLaunchBytes, st));
     psa::FillArgs fa;
     fa.a = s->a_dev; fa.b = s->b_dev; fa.n = s->n; fa.r0 = r0; fa.r1 = r1; fa.c0 = s->c0;
-    fa.W = o.W > 0 ? o.W : s->W; fa.Q = o.W > 0 ? (o.W + 63 + 63) / 64 : s->Q; fa.Wpad = s->Wpad;
+    fa.W = o.W > 0 ? o.W : s->W; fa.Q = o.W > 0 ? steps_q(o.W) : s->Q; fa.Wpad = s->Wpad;
     const bool with_codes = o.codes < 0 ? s->codes != nullptr : o.codes != 0;
     fa.left = left_dev;
     fa.corner = s->small + 4 * s->corner_cur;
-    fa.corner_next = s->small + 4 * (s->corner_cur ^ 1);
+    fa.corner_next = s->small + 4 * ((s->corner_cur + 1) % kCornerSlots);
     fa.right = right_dev;
-    fa.final_triple = s->small + 8;
+    fa.left_done = o.left_done; fa.right_done = o.right_done;
+    fa.final_triple = s->small + kFinalWord;
     fa.ring = s->ring;
     fa.codes = with_codes ? (o.codes_base ? o.codes_base : s->codes) : nullptr;
     fa.leftcol = with_codes ? s->leftcol : nullptr;
-    fa.ticket = s->ctrl;
+    fa.ticket = launch_ctrl;
     fa.abort_flag = s->ctrl + kAbortWord;
     fa.prof = nullptr;
     fa.ckpt = s->ckpt; fa.band_strips = s->band_rows / 64;
+    out->base = fa; out->a_ids = s->a_ids; out->eqtab = s->eqtab; out->tab_pitch = s->tab_pitch;
+    *with_codes_out = with_codes;
+    s->corner_cur = (s->corner_cur + 1) % kCornerSlots;
+    s->next_r0 = r1;
+    return PSA_OK;
+}
+
+unsigned groups_of(const psa::FillArgs2& j) {
+    const int64_t strips = (j.base.r1 - j.base.r0 + 63) / 64;
+    return (unsigned)((strips + psa::kNW - 1) / psa::kNW);
+}
+
+// One launch of fill_strips_v2 over up to kMaxJobs stripes.  order_dev: ticket -> job << 24 | group (null: one job).
+int launch_fill_v2(const psa::FillArgs2* jobs, int njobs, const uint32_t* order_dev, unsigned total_groups,
+                   unsigned* ticket_dev, bool with_codes, size_t keepout_bytes, hipStream_t st) {
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[with_codes]) {   // dynamic LDS beyond 64 KB has to be allowed once per kernel
+        if (with_codes) HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
+        else HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
+        attr_set[with_codes] = true;
+    }
+    psa::FillBatch fb;
+    memset(&fb, 0, sizeof fb);
+    for (int j = 0; j < njobs; ++j) fb.job[j] = jobs[j];
+    fb.njobs = njobs; fb.order = order_dev; fb.ticket = ticket_dev;
+    if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
+    else hipLaunchKernelGGL(psa::fill_strips_v2<false>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
+    HIP_TRY(hipGetLastError());
+    return PSA_OK;
+}
+
+int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev, void* stream,
+                   const FillOpts& o) {
+    if (!s) return fail(PSA_E_ARG, "psa_stripe_fill_rows: null stripe");
+    DeviceGuard g(s->device);
+    if (g.rc) return g.rc;
+    hipStream_t st = (hipStream_t)stream;
+    psa::FillArgs2 fb;
+    bool with_codes = false;
+    if (int rc = prepare_fill(s, r0, r1, left_dev, right_dev, st, o, &fb, &with_codes)) return rc;
     const char* prof_path = getenv("PSA_PROFILE_STRIPS");
     psa::u64* prof_dev = nullptr;
-    const unsigned nstrips_prof = (unsigned)((r1 - r0 + 63) / 64);
+    const unsigned strips = (unsigned)((r1 - r0 + 63) / 64);
     if (prof_path && s->use_v2) {
-        size_t prof_words = 4 * (size_t)nstrips_prof;
+        size_t prof_words = 4 * (size_t)strips;
         HIP_TRY(hipMalloc(&prof_dev, sizeof(psa::u64) * prof_words));
         HIP_TRY(hipMemsetAsync(prof_dev, 0, sizeof(psa::u64) * prof_words, st));
-        fa.prof = prof_dev;
+        fb.base.prof = prof_dev;
     }
-    const unsigned strips = (unsigned)((r1 - r0 + 63) / 64);
     HIP_TRY(hipEventRecord(s->ev[0], st));
     if (s->use_v2) {
-        psa::FillArgs2 fb;
-        fb.base = fa; fb.a_ids = s->a_ids; fb.eqtab = s->eqtab; fb.tab_pitch = s->tab_pitch;
-        const unsigned wgs = (strips + psa::kNW - 1) / psa::kNW;
-        if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(wgs), dim3(psa::kNW * 64), 0, st, fb);
-        else hipLaunchKernelGGL(psa::fill_strips_v2<false>, dim3(wgs), dim3(psa::kNW * 64), 0, st, fb);
-    } else if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fa);
-    else hipLaunchKernelGGL(psa::fill_strips_v1<false>, dim3(strips), dim3(64), 0, st, fa);
+        if (int rc = launch_fill_v2(&fb, 1, nullptr, groups_of(fb), fb.base.ticket, with_codes, psa::kKeepoutAloneBytes, st)) return rc;
+    } else if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fb.base);
+    else hipLaunchKernelGGL(psa::fill_strips_v1<false>, dim3(strips), dim3(64), 0, st, fb.base);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[1], st));
     s->fill_timed = true;
     if (prof_dev) {  // diagnostic only: dump per-strip start/end ticks and placement
-        std::vector<psa::u64> h(4 * (size_t)nstrips_prof);
+        std::vector<psa::u64> h(4 * (size_t)strips);
         HIP_TRY(hipStreamSynchronize(st));   // (a stream created non-blocking is not ordered against the copy below)
         HIP_TRY(hipMemcpy(h.data(), prof_dev, sizeof(psa::u64) * h.size(), hipMemcpyDeviceToHost));
         std::string pp = prof_path;
@@ -345,79 +393,48 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
         }
         if (FILE* f = fopen(pp.c_str(), "w")) {
             fprintf(f, "strip,start,end,xcc,hwid,wait_in,wait_room\n");
-            for (unsigned k = 0; k < nstrips_prof; ++k)
+            for (unsigned k = 0; k < strips; ++k)
                 fprintf(f, "%u,%lld,%lld,%llu,%llu,%llu,%llu\n", k, (long long)(h[4 * k] - h[0]),
                         (long long)(h[4 * k + 1] - h[0]), h[4 * k + 2] >> 32, h[4 * k + 2] & 0xffffffffu,
                         h[4 * k + 3] & 0xffffffffu, h[4 * k + 3] >> 32);
             fclose(f);
         }
         hipFree(prof_dev);
-        prof_dev = nullptr;
     }
-    s->corner_cur ^= 1;
-    s->next_r0 = r1;
     return PSA_OK;
 }
-}  // namespace
 
-extern "C" {
-
-static int check_abort(psa_stripe* s, hipStream_t st) {
-    unsigned ctrl[kAbortWord + 1] = {0};
-    HIP_TRY(hipMemcpyAsync(ctrl, s->ctrl, sizeof ctrl, hipMemcpyDeviceToHost, st));
+int check_abort(psa_stripe* s, hipStream_t st) {
+    unsigned ab = 0;
+    HIP_TRY(hipMemcpyAsync(&ab, s->ctrl + kAbortWord, sizeof ab, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-#ifdef PSA_FILL_STATS
-    {
-        unsigned long long stats[4] = {0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(stats, s->ctrl + 48, sizeof stats, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (getenv("PSA_FILL_STATS") && ctrl[0])
-            fprintf(stderr, "fillstats: groups %u wait_before_start_us %.1f wave0_work_us %.1f wg_resident_us %.1f (means per group)\n",
-                    ctrl[0], stats[0] / 100.0 / ctrl[0], stats[1] / 100.0 / ctrl[0], stats[2] / 100.0 / ctrl[0]);
-    }
-#endif
-    if (ctrl[kAbortWord])
-        return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired (workgroups started %u, "
-                    "chain front at workgroup %u)", ctrl[0], ctrl[psa::kFrontWord]);
+    if (ab) return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above (or for the stripe on its left) expired");
     return PSA_OK;
 }
 
-int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]) {
-    if (!s || !triple_out) return fail(PSA_E_ARG, "psa_stripe_final: null argument");
-    if (s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_final: rows filled up to %lld of %lld",
-                                        (long long)s->next_r0, (long long)s->n);
-    hipStream_t st = (hipStream_t)stream;
-    if (int rc = enter_device(s)) return rc;
-    if (int rc = check_abort(s, st)) return rc;
-    HIP_TRY(hipMemcpyAsync(triple_out, s->small + 8, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));   // (on the stripe's own stream: the null stream would order it against other stripes' work)
-    return PSA_OK;
-}
-
-}  // extern "C"
-
-namespace {
 struct TraceOpts {
     const uint8_t* codes_base = nullptr;    // banded mode: where strip 0's codes would lie
     int W = 0;                              // > 0: the codes were written by a fill of the first W columns
     int64_t row_min = 0;                    // the codes cover rows > row_min only
 };
-int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai, int32_t* bj,
-                   int64_t cap, int64_t* len_io, void* stream, const TraceOpts& o);
-}  // namespace
 
-extern "C" {
-
-int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai, int32_t* bj,
-                         int64_t cap, int64_t* len_io, void* stream) {
-    if (s && s->band_rows) return fail(PSA_E_STATE, "psa_stripe_traceback: a banded stripe is driven by psa_align_banded");
-    if (s && s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_traceback: fill is not complete");
-    return traceback_impl(s, i_io, j_io, k_io, ai, bj, cap, len_io, stream, TraceOpts());
+int make_trace_args(psa_stripe* s, const TraceOpts& o, psa::TraceArgs* ta) {
+    ta->codes = o.codes_base ? o.codes_base : s->codes; ta->c0 = s->c0; ta->cap = s->tb_cap;
+    ta->a = s->a_dev; ta->b = s->b_dev; ta->leftcol = s->leftcol;
+    ta->toprow = (o.row_min > 0 && s->band_rows > 0) ? s->ckpt + (size_t)(o.row_min / s->band_rows) * (size_t)s->Wpad : nullptr;
+    if (o.row_min > 0 && !ta->toprow) return fail(PSA_E_STATE, "traceback: a row limit needs the checkpoint row of a banded stripe");
+    ta->W = o.W > 0 ? o.W : s->W; ta->Q = o.W > 0 ? steps_q(o.W) : s->Q;
+    ta->row_min = o.row_min;
+    ta->out_ai = s->tb_ai; ta->out_bj = s->tb_bj; ta->state = s->tb_state;
+    ta->n = s->n; ta->start_triple = nullptr;
+    return PSA_OK;
 }
 
-}  // extern "C"
+// the fast walk keeps its state in 32-bit registers: coordinates and tile ids must fit
+bool walk_fits32(const psa_stripe* s, int Q) {
+    return s->n < 0x7fff0000LL && s->c0 + s->W < 0x7fff0000LL && ((s->n + 63) / 64) * (int64_t)Q < 0x7fff0000LL;
+}
 
-namespace {
 int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai, int32_t* bj,
                    int64_t cap, int64_t* len_io, void* stream, const TraceOpts& o) {
     if (!s || !i_io || !j_io || !k_io || !ai || !bj || !len_io) return fail(PSA_E_ARG, "psa_stripe_traceback: null argument");
@@ -425,25 +442,17 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     if (*k_io < 1 || *k_io > 3 || *i_io < 0 || *i_io > s->n || *j_io < 0 || *j_io > s->c1 + 1)
         return fail(PSA_E_ARG, "psa_stripe_traceback: bad state (%lld,%lld,%d)", (long long)*i_io, (long long)*j_io, *k_io);
     hipStream_t st = (hipStream_t)stream;
-    if (int rc = enter_device(s)) return rc;
+    DeviceGuard g(s->device);
+    if (g.rc) return g.rc;
     if (int rc = check_abort(s, st)) return rc;
     int64_t state[12] = {*i_io, *j_io, *k_io, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(s->tb_state, state, sizeof state, hipMemcpyHostToDevice, st));
     psa::TraceArgs ta;
-    ta.codes = o.codes_base ? o.codes_base : s->codes; ta.c0 = s->c0; ta.cap = s->tb_cap;
-    ta.a = s->a_dev; ta.b = s->b_dev; ta.leftcol = s->leftcol;
-    ta.toprow = (o.row_min > 0 && s->band_rows > 0) ? s->ckpt + (size_t)(o.row_min / s->band_rows) * (size_t)s->Wpad : nullptr;
-    if (o.row_min > 0 && !ta.toprow) return fail(PSA_E_STATE, "traceback: a row limit needs the checkpoint row of a banded stripe");
-    ta.W = o.W > 0 ? o.W : s->W; ta.Q = o.W > 0 ? (o.W + 63 + 63) / 64 : s->Q;
-    ta.row_min = o.row_min;
-    ta.out_ai = s->tb_ai; ta.out_bj = s->tb_bj; ta.state = s->tb_state;
+    if (int rc = make_trace_args(s, o, &ta)) return rc;
     HIP_TRY(hipEventRecord(s->ev[2], st));
     {
         const char* force = getenv("PSA_TRACEBACK_KERNEL");
-        // the fast kernel keeps the walk in 32-bit registers: coordinates and tile ids must fit
-        const bool fits32 = s->n < 0x7fff0000LL && s->c0 + s->W < 0x7fff0000LL &&
-                            ((s->n + 63) / 64) * (int64_t)ta.Q < 0x7fff0000LL;
-        if ((force && !strcmp(force, "v1")) || !fits32) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
+        if ((force && !strcmp(force, "v1")) || !walk_fits32(s, ta.Q)) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
         else hipLaunchKernelGGL(psa::traceback_wave, dim3(1), dim3(64), 0, st, ta);
     }
     HIP_TRY(hipGetLastError());
@@ -451,8 +460,12 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     s->tb_timed = true;
     HIP_TRY(hipMemcpyAsync(state, s->tb_state, sizeof state, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: len %lld iterations %lld runs/tiles %lld misses %lld\n", (long long)state[4], (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)state[7]);
-    if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld; sections %lld %lld %lld %lld\n", (long long)state[8], (long long)state[9], (long long)(state[10] >> 32), (long long)(state[10] & 0xffffffff), (long long)(state[11] >> 32), (long long)(state[11] & 0xffffffff));
+    if (getenv("PSA_TRACE_STATS")) {
+        fprintf(stderr, "traceback: len %lld passes %lld tiles %lld single-cell steps %lld misses %lld\n", (long long)state[4],
+                (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)(state[7] >> 32), (long long)(state[7] & 0xffffffff));
+        fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld; sections %lld %lld %lld %lld\n", (long long)state[8], (long long)state[9],
+                (long long)(state[10] >> 32), (long long)(state[10] & 0xffffffff), (long long)(state[11] >> 32), (long long)(state[11] & 0xffffffff));
+    }
     if (state[5] == 2) return fail(PSA_E_KERNEL, "traceback: winner codes failed the decode check (values that cannot belong to one cell)");
     if (state[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow");
     const int64_t got = state[4];
@@ -468,13 +481,89 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
         return fail(PSA_E_KERNEL, "traceback: head stripe stopped before the matrix boundary");
     return PSA_OK;
 }
+
 }  // namespace
 
 extern "C" {
 
+const char* psa_last_error(void) { return g_err.c_str(); }
+const char* psa_version(void) { return "psa-hip 0.2 (gfx950)"; }
+
+int psa_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int psa_set_device(int device) {
+    if (int rc = need_device()) return rc;
+    HIP_TRY(hipSetDevice(device));
+    return PSA_OK;
+}
+
+void psa_free(void* p) { free(p); }
+
+void psa_stripe_destroy(psa_stripe* s) { free_stripe(s); }
+
+int psa_stripe_create(psa_stripe** out, const uint8_t* a, int64_t n, const uint8_t* b, int64_t m,
+                      int64_t c0, int64_t c1, uint32_t flags) {
+    if (!out) return fail(PSA_E_ARG, "psa_stripe_create: out is null");
+    *out = nullptr;
+    if (n < 1 || m < 1 || c0 < 0 || c1 <= c0 || c1 > m || !a || !b)
+        return fail(PSA_E_ARG, "psa_stripe_create: need n>=1, m>=1, 0<=c0<c1<=m (n=%lld m=%lld c0=%lld c1=%lld)",
+                    (long long)n, (long long)m, (long long)c0, (long long)c1);
+    if (n > (1LL << 27) || m > (1LL << 27)) return fail(PSA_E_ARG, "sequence longer than 2^27 is not supported");
+    if (int rc = need_device()) return rc;
+    psa_stripe* s = nullptr;
+    if (int rc = alloc_stripe(&s, n, (int)(c1 - c0), flags, c0 > 0)) return rc;
+    int rc = bind_stripe(s, n, m, c0, c1);
+    if (rc == PSA_OK) rc = upload_host(s, a, b, nullptr);
+    if (rc == PSA_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail(PSA_E_HIP, "psa_stripe_create: upload failed");
+    if (rc != PSA_OK) { free_stripe(s); return rc; }
+    *out = s;
+    return PSA_OK;
+}
+
+int psa_stripe_set_sequences_dev(psa_stripe* s, const uint8_t* a_dev, const uint8_t* b_dev, void* stream) {
+    if (!s || !a_dev || !b_dev) return fail(PSA_E_ARG, "psa_stripe_set_sequences_dev: null argument");
+    DeviceGuard g(s->device);
+    if (g.rc) return g.rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(s->a_dev, a_dev, (size_t)s->n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->b_dev, b_dev, (size_t)s->W, hipMemcpyDeviceToDevice, st));
+    return rebuild_tables(s, st, -1);
+}
+
+int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev, int32_t* right_dev,
+                         void* stream) {
+    if (s && s->band_rows) return fail(PSA_E_STATE, "psa_stripe_fill_rows: a banded stripe is driven by psa_align_banded");
+    return fill_rows_impl(s, r0, r1, left_dev, right_dev, stream, FillOpts());
+}
+
+int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]) {
+    if (!s || !triple_out) return fail(PSA_E_ARG, "psa_stripe_final: null argument");
+    if (s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_final: rows filled up to %lld of %lld",
+                                        (long long)s->next_r0, (long long)s->n);
+    hipStream_t st = (hipStream_t)stream;
+    DeviceGuard g(s->device);
+    if (g.rc) return g.rc;
+    if (int rc = check_abort(s, st)) return rc;
+    HIP_TRY(hipMemcpyAsync(triple_out, s->small + kFinalWord, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));   // (on the stripe's own stream: the null stream would order it against other stripes' work)
+    return PSA_OK;
+}
+
+int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai, int32_t* bj,
+                         int64_t cap, int64_t* len_io, void* stream) {
+    if (s && s->band_rows) return fail(PSA_E_STATE, "psa_stripe_traceback: a banded stripe is driven by psa_align_banded");
+    if (s && s->next_r0 != s->n) return fail(PSA_E_STATE, "psa_stripe_traceback: fill is not complete");
+    return traceback_impl(s, i_io, j_io, k_io, ai, bj, cap, len_io, stream, TraceOpts());
+}
+
 int psa_stripe_last_fill_ms(psa_stripe* s, float* ms_out) {
     if (!s || !ms_out || !s->fill_timed) return fail(PSA_E_STATE, "no fill has been timed");
-    if (int rc = enter_device(s)) return rc;
+    DeviceGuard g(s->device);
+    if (g.rc) return g.rc;
     HIP_TRY(hipEventSynchronize(s->ev[1]));
     HIP_TRY(hipEventElapsedTime(ms_out, s->ev[0], s->ev[1]));
     return PSA_OK;
@@ -482,7 +571,8 @@ int psa_stripe_last_fill_ms(psa_stripe* s, float* ms_out) {
 
 int psa_stripe_last_traceback_ms(psa_stripe* s, float* ms_out) {
     if (!s || !ms_out || !s->tb_timed) return fail(PSA_E_STATE, "no traceback has been timed");
-    if (int rc = enter_device(s)) return rc;
+    DeviceGuard g(s->device);
+    if (g.rc) return g.rc;
     HIP_TRY(hipEventSynchronize(s->ev[3]));
     HIP_TRY(hipEventElapsedTime(ms_out, s->ev[2], s->ev[3]));
     return PSA_OK;
@@ -509,56 +599,154 @@ int psa_finish_alignment(int32_t* ai, int32_t* bj, int64_t len, int64_t cap, int
 
 namespace {
 
+// ---- the column stripes of one pair on one GPU (simple.cpp:90-99, 261-277) ----
 struct StripeSet {
+    int device = -1;
+    int64_t n = 0, m = 0;
+    int p = 0;
+    uint32_t flags = 0;
     std::vector<psa_stripe*> st;
-    std::vector<int32_t*> edge;  // device boundary buffers between consecutive stripes
-    ~StripeSet() {
-        for (auto* s : st) psa_stripe_destroy(s);
+    std::vector<int32_t*> edge;  // device boundary buffers between consecutive stripes: int32[3][n]
+    uint32_t* order = nullptr;   // ticket order of the one-launch fill
+    size_t order_cap = 0;
+    void clear() {
+        for (auto* s : st) free_stripe(s);
         for (auto* e : edge) hipFree(e);
+        hipFree(order);
+        st.clear(); edge.clear(); order = nullptr; order_cap = 0; p = 0;
     }
 };
 
-int64_t chunk_rows_default() {
+// The stripe objects of the most recent whole-pair call of this thread are kept and reused when the next
+// call has the same shape (sizes, p, flags, device): no allocation on the second ./simple-style call.
+// Never freed by a destructor (the HIP runtime may be gone by then); psa_release_cache() frees it.
+thread_local StripeSet* g_cache = nullptr;
+
+int64_t chunk_rows_env() {
     if (const char* e = getenv("PSA_CHUNK_ROWS")) {
         long long v = atoll(e);
         if (v >= 64) return (v / 64) * 64;
     }
-    return 8192;
+    return 0;
 }
 
-// Column stripes exactly as simple.cpp:90-99 cuts them; zero-width stripes (p > m) own no cell.
-int run_stripes(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, uint32_t flags,
-                StripeSet& set, int32_t triple[3]) {
-    const int64_t block = m / p;
-    for (int id = 0; id < p; ++id) {
-        const int64_t c0 = (int64_t)id * block;
-        const int64_t c1 = (id == p - 1) ? m : c0 + block;
-        if (c1 == c0) continue;
-        psa_stripe* s = nullptr;
-        if (int rc = psa_stripe_create(&s, a, n, b, m, c0, c1, flags)) return rc;
-        set.st.push_back(s);
-    }
-    const size_t ns = set.st.size();
-    const int64_t chunk = ns > 1 ? std::min<int64_t>(chunk_rows_default(), ((n + 63) / 64) * 64) : n;
-    for (size_t g = 0; g + 1 < ns; ++g) {
-        int32_t* e = nullptr;
-        HIP_TRY(hipMalloc(&e, sizeof(int32_t) * 3 * (size_t)chunk));
-        set.edge.push_back(e);
-    }
-    for (int64_t r0 = 0; r0 < n; r0 += chunk) {
-        const int64_t r1 = std::min(n, r0 + chunk);
-        for (size_t g = 0; g < ns; ++g) {
-            const int32_t* left = g ? set.edge[g - 1] : nullptr;
-            int32_t* right = (g + 1 < ns) ? set.edge[g] : nullptr;
-            if (int rc = psa_stripe_fill_rows(set.st[g], r0, r1, left, right, nullptr)) return rc;
+int get_stripes(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, uint32_t flags, StripeSet** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!g_cache) g_cache = new StripeSet();
+    StripeSet& set = *g_cache;
+    const bool hit = set.device == dev && set.n == n && set.m == m && set.p == p && set.flags == flags && !set.st.empty();
+    if (!hit) {
+        set.clear();
+        set.device = dev; set.n = n; set.m = m; set.flags = flags;
+        const int64_t block = m / p;   // column stripes exactly as simple.cpp:90-99 cuts them; zero-width stripes (p > m) own no cell
+        for (int id = 0; id < p; ++id) {
+            const int64_t c0 = (int64_t)id * block;
+            const int64_t c1 = (id == p - 1) ? m : c0 + block;
+            if (c1 == c0) continue;
+            psa_stripe* s = nullptr;
+            int rc = alloc_stripe(&s, n, (int)(c1 - c0), flags, c0 > 0);
+            if (rc == PSA_OK) rc = bind_stripe(s, n, m, c0, c1);
+            if (rc != PSA_OK) { free_stripe(s); set.clear(); return rc; }
+            set.st.push_back(s);
         }
+        for (size_t g = 0; g + 1 < set.st.size(); ++g) {
+            int32_t* e = nullptr;
+            if (hipMalloc(&e, sizeof(int32_t) * 3 * (size_t)n) != hipSuccess) { set.clear(); return fail(PSA_E_NOMEM, "boundary buffer allocation failed"); }
+            set.edge.push_back(e);
+        }
+        set.p = p;
     }
+    for (auto* s : set.st) {
+        if (int rc = bind_stripe(s, n, m, s->c0, s->c1)) return rc;
+        if (int rc = upload_host(s, a, b, nullptr)) return rc;
+    }
+    *out = &set;
+    return PSA_OK;
+}
+
+// Fill every stripe.  Default: ONE launch per group of up to kMaxJobs stripes -- the stripes are jobs of the
+// same launch, stripe g+1 picks up the rows of its left boundary as stripe g's strips finish them (flags in
+// device memory), and the ticket order lets it trail by about the time a strip takes.  With PSA_CHUNK_ROWS
+// set (tests), or for alphabets the table kernel does not take: one launch per stripe and row chunk, in
+// stream order, as a chain of GPUs would run them.
+int run_stripes(StripeSet& set, int32_t triple[3]) {
+    const size_t ns = set.st.size();
+    const int64_t n = set.n;
+    bool all_v2 = true;
+    for (auto* s : set.st) all_v2 = all_v2 && s->use_v2;
+    const int64_t chunk_env = chunk_rows_env();
+    if (chunk_env > 0 || !all_v2) {
+        const int64_t chunk = (ns > 1 && chunk_env > 0) ? std::min<int64_t>(chunk_env, ((n + 63) / 64) * 64) : n;
+        for (int64_t r0 = 0; r0 < n; r0 += chunk) {
+            const int64_t r1 = std::min(n, r0 + chunk);
+            for (size_t g = 0; g < ns; ++g) {
+                // (chunk buffers are cut out of the whole-column buffers: [3][rows] at the front)
+                const int32_t* left = g ? set.edge[g - 1] : nullptr;
+                int32_t* right = (g + 1 < ns) ? set.edge[g] : nullptr;
+                if (int rc = fill_rows_impl(set.st[g], r0, r1, left, right, nullptr, FillOpts())) return rc;
+            }
+        }
+        return psa_stripe_final(set.st.back(), nullptr, triple);
+    }
+    const bool with_codes = set.st[0]->codes != nullptr;
+    for (size_t g0 = 0; g0 < ns; g0 += psa::kMaxJobs) {
+        const int nj = (int)std::min<size_t>(psa::kMaxJobs, ns - g0);
+        psa::FillArgs2 jobs[psa::kMaxJobs];
+        unsigned groups[psa::kMaxJobs], delay[psa::kMaxJobs];
+        unsigned total = 0;
+        for (int j = 0; j < nj; ++j) {
+            psa_stripe* s = set.st[g0 + j];
+            const size_t g = g0 + j;
+            FillOpts o;
+            if (j > 0) o.left_done = set.st[g - 1]->done;          // inside this launch
+            if (j + 1 < nj) o.right_done = s->done;
+            if (o.right_done) HIP_TRY(hipMemsetAsync(s->done, 0, sizeof(unsigned) * (size_t)((n + 63) / 64), nullptr));
+            bool wc = false;
+            if (int rc = prepare_fill(s, 0, n, g ? set.edge[g - 1] : nullptr, (g + 1 < ns) ? set.edge[g] : nullptr, nullptr, o,
+                                      &jobs[j], &wc)) return rc;
+            groups[j] = groups_of(jobs[j]);
+            total += groups[j];
+            // stripe j's group r can start once stripe j-1's group r is through: about (W + 64) steps, while
+            // groups of one stripe start about 4 x 90 steps apart
+            delay[j] = j ? delay[j - 1] + (unsigned)((set.st[g - 1]->W + 64 + 359) / 360) + 1 : 0;
+        }
+        const uint32_t* order_dev = nullptr;
+        if (nj > 1) {
+            std::vector<uint32_t> order;
+            order.reserve(total);
+            const unsigned last_slot = delay[nj - 1] + groups[nj - 1];
+            for (unsigned slot = 0; slot < last_slot; ++slot)
+                for (int j = 0; j < nj; ++j)
+                    if (slot >= delay[j] && slot - delay[j] < groups[j]) order.push_back(((uint32_t)j << psa::kOrderJobShift) | (slot - delay[j]));
+            if (set.order_cap < order.size()) {
+                hipFree(set.order);
+                set.order = nullptr; set.order_cap = 0;
+                HIP_TRY(hipMalloc(&set.order, sizeof(uint32_t) * order.size()));
+                set.order_cap = order.size();
+            }
+            HIP_TRY(hipMemcpy(set.order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice));
+            order_dev = set.order;
+        }
+        psa_stripe* s0 = set.st[g0];
+        HIP_TRY(hipEventRecord(s0->ev[0], nullptr));
+        if (int rc = launch_fill_v2(jobs, nj, order_dev, total, jobs[0].base.ticket, with_codes,
+                                    nj > 1 ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes, nullptr)) return rc;
+        HIP_TRY(hipEventRecord(s0->ev[1], nullptr));
+        s0->fill_timed = true;
+    }
+    for (size_t g = 0; g + 1 < ns; ++g)   // (an expired wait anywhere fails the call, not only in the last stripe)
+        if (int rc = check_abort(set.st[g], nullptr)) return rc;
     return psa_stripe_final(set.st.back(), nullptr, triple);
 }
 
 }  // namespace
 
 extern "C" {
+
+void psa_release_cache(void) {
+    if (g_cache) { g_cache->clear(); delete g_cache; g_cache = nullptr; }
+}
 
 int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, int32_t* score_out,
               int32_t triple_out[3]) {
@@ -569,8 +757,10 @@ int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, i
     if (n == 0) { t[0] = -1; t[1] = 0; t[2] = (int32_t)-(2 + m); }       // loop of simple.cpp:122 never runs
     else if (m == 0) { t[0] = -1; t[1] = (int32_t)-(2 + n); t[2] = -1; } // only column 0 exists (simple.cpp:124-133)
     else {
-        StripeSet set;
-        if (int rc = run_stripes(a, n, b, m, p, 0, set, t)) return rc;
+        if (n > (1LL << 27) || m > (1LL << 27)) return fail(PSA_E_ARG, "sequence longer than 2^27 is not supported");
+        StripeSet* set = nullptr;
+        if (int rc = get_stripes(a, n, b, m, p, 0, &set)) return rc;
+        if (int rc = run_stripes(*set, t)) return rc;
     }
     pick3(t, score_out);
     if (triple_out) memcpy(triple_out, t, sizeof t);
@@ -587,13 +777,18 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, i
     *len_out = 0;
     const int64_t cap = 2 * (n + m) + 2;
     if (n > 0 && m > 0) {
-        // codes of the whole matrix (1 B per cell) against what the device has free: beyond 70 %
-        // of it -- or when PSA_BAND_ROWS asks for it -- align in linear space
+        if (n > (1LL << 27) || m > (1LL << 27)) return fail(PSA_E_ARG, "sequence longer than 2^27 is not supported");
+        // codes of the whole matrix (1 B per cell) against what the device has free (plus what this thread's
+        // cached stripes of the same shape already hold): beyond 70 % of it -- or when PSA_BAND_ROWS asks
+        // for it -- align in linear space
         size_t free_b = 0, total_b = 0;
         const double code_bytes = (double)n * (double)m;
         const bool forced = getenv("PSA_BAND_ROWS") != nullptr;
-        if (forced || (hipMemGetInfo(&free_b, &total_b) == hipSuccess && code_bytes > 0.7 * (double)free_b))
+        const bool cached = g_cache && g_cache->n == n && g_cache->m == m && g_cache->p == p && g_cache->flags == PSA_F_TRACEBACK;
+        if (forced || (!cached && hipMemGetInfo(&free_b, &total_b) == hipSuccess && code_bytes > 0.7 * (double)free_b)) {
+            psa_release_cache();
             return psa_align_banded(a, n, b, m, 0, score_out, ai_out, bj_out, len_out);
+        }
     }
     int32_t* ai = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
     int32_t* bj = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
@@ -604,14 +799,15 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, i
     if (n == 0) { t[0] = -1; t[1] = 0; t[2] = (int32_t)-(2 + m); }
     else if (m == 0) { t[0] = -1; t[1] = (int32_t)-(2 + n); t[2] = -1; }
     else {
-        StripeSet set;
-        rc = run_stripes(a, n, b, m, p, PSA_F_TRACEBACK, set, t);
+        StripeSet* set = nullptr;
+        rc = get_stripes(a, n, b, m, p, PSA_F_TRACEBACK, &set);
+        if (rc == PSA_OK) rc = run_stripes(*set, t);
         if (rc == PSA_OK) {
             int32_t v;
             int64_t i = n, j = m;
             int k = pick3(t, &v);
-            for (size_t g = set.st.size(); g-- > 0 && rc == PSA_OK;) {
-                rc = psa_stripe_traceback(set.st[g], &i, &j, &k, ai, bj, cap, &len, nullptr);
+            for (size_t g = set->st.size(); g-- > 0 && rc == PSA_OK;) {
+                rc = psa_stripe_traceback(set->st[g], &i, &j, &k, ai, bj, cap, &len, nullptr);
                 if (i == 0 || j == 0) break;
             }
         }
@@ -637,8 +833,7 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
     int rc = psa_stripe_create(&s, a, n, b, m, 0, m, PSA_F_TRACEBACK | PSA_F_BANDED);
     g_band_rows_request = 0;
     if (rc) return rc;
-    StripeSet owner;
-    owner.st.push_back(s);
+    struct Owner { psa_stripe* s; ~Owner() { free_stripe(s); } } owner{s};
     const int64_t B = s->band_rows;
     // pass 1: score only, one launch; the last strip of every band leaves its bottom row in ckpt
     {
@@ -663,7 +858,7 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
         const int64_t r0 = bnd * B, r1 = std::min(n, r0 + B);
         if (r0 > 0 && i - (k != 2) <= r0) continue;            // the walk left this band without a step in it
         const int Wr = (int)std::min<int64_t>(s->W, j);
-        const int Qr = (Wr + 63 + 63) / 64;
+        const int Qr = steps_q(Wr);
         uint8_t* base = (uint8_t*)((uintptr_t)s->codes - (uintptr_t)psa::code_tile_offset(r0 / 64, Qr, 0));
         if (getenv("PSA_TRACE_STATS")) fprintf(stderr, "banded: band %lld rows %lld..%lld columns %d, walk at (%lld,%lld,%d)\n", (long long)bnd, (long long)r0, (long long)r1, Wr, (long long)i, (long long)j, k);
         FillOpts fo;
@@ -678,6 +873,349 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
     *score_out = v;
     *ai_out = ai; *bj_out = bj; *len_out = len;
     return PSA_OK;
+}
+
+}  // extern "C"
+
+
+// ---- several pairs in ONE launch (psa_many_*, psa_align_many): see include/psa.h ----
+struct psa_many {
+    int device = 0;
+    int slots = 0;
+    uint32_t flags = 0;
+    int64_t n_cap = 0, m_cap = 0;
+    std::vector<psa_stripe*> st;
+    std::vector<char> bound;        // 0: free, 1: holds a pair with cells, 2: holds a pair without cells (n or m is 0)
+    std::vector<int64_t> n, m;
+    hipStream_t stream = nullptr;
+    unsigned* ticket = nullptr;     // 256 bytes
+    uint32_t* order = nullptr;
+    size_t order_cap = 0;
+    int64_t* h_state = nullptr;     // pinned: slots x 16
+    int32_t* h_triple = nullptr;    // pinned: slots x 4
+    unsigned* h_abort = nullptr;    // pinned: slots
+    std::vector<int32_t*> h_ai, h_bj;   // pinned: reversed columns as the walk emitted them
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // fill start / end, walks end, results on the host
+    bool launched = false;
+};
+
+namespace {
+
+void free_many(psa_many* e) {
+    if (!e) return;
+    DeviceGuard g(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    for (auto* s : e->st) free_stripe(s);
+    for (auto* p : e->h_ai) hipHostFree(p);
+    for (auto* p : e->h_bj) hipHostFree(p);
+    hipFree(e->ticket); hipFree(e->order);
+    hipHostFree(e->h_state); hipHostFree(e->h_triple); hipHostFree(e->h_abort);
+    for (auto& x : e->ev) if (x) hipEventDestroy(x);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int many_bind(psa_many* e, int slot, int64_t n, int64_t m) {
+    if (!e || slot < 0 || slot >= e->slots) return fail(PSA_E_ARG, "psa_many: no such slot");
+    if (n < 0 || m < 0 || n > e->n_cap || m > e->m_cap)
+        return fail(PSA_E_ARG, "psa_many: pair of %lld x %lld does not fit the engine (%lld x %lld)", (long long)n, (long long)m,
+                    (long long)e->n_cap, (long long)e->m_cap);
+    e->n[slot] = n; e->m[slot] = m;
+    e->bound[slot] = (n == 0 || m == 0) ? 2 : 1;
+    if (e->bound[slot] == 1) return bind_stripe(e->st[slot], n, m, 0, m);
+    return PSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void psa_many_destroy(psa_many* e) { free_many(e); }
+
+int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uint32_t flags) {
+    if (!out) return fail(PSA_E_ARG, "psa_many_create: out is null");
+    *out = nullptr;
+    if (slots < 1 || slots > psa::kMaxJobs) return fail(PSA_E_ARG, "psa_many_create: 1 to %d slots", psa::kMaxJobs);
+    if (n_cap < 1 || m_cap < 1 || n_cap > (1LL << 27) || m_cap > (1LL << 27)) return fail(PSA_E_ARG, "psa_many_create: bad capacity");
+    if (flags & PSA_F_BANDED) return fail(PSA_E_ARG, "psa_many_create: banded alignment goes through psa_align_banded");
+    if (int rc = need_device()) return rc;
+    psa_many* e = new psa_many();
+    if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
+    e->slots = slots; e->flags = flags; e->n_cap = n_cap; e->m_cap = m_cap;
+    e->bound.assign(slots, 0); e->n.assign(slots, 0); e->m.assign(slots, 0);
+#define MANY_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            free_many(e);                                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? PSA_E_NOMEM : PSA_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+        }                                                                                                      \
+    } while (0)
+    MANY_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto& x : e->ev) MANY_TRY(hipEventCreate(&x));
+    MANY_TRY(hipMalloc(&e->ticket, 256));
+    MANY_TRY(hipHostMalloc(&e->h_state, sizeof(int64_t) * 16 * slots));
+    MANY_TRY(hipHostMalloc(&e->h_triple, sizeof(int32_t) * 4 * slots));
+    MANY_TRY(hipHostMalloc(&e->h_abort, sizeof(unsigned) * slots));
+    for (int k = 0; k < slots; ++k) {
+        psa_stripe* s = nullptr;
+        if (int rc = alloc_stripe(&s, n_cap, (int)m_cap, flags, false)) { free_many(e); return rc; }
+        e->st.push_back(s);
+        if (flags & PSA_F_TRACEBACK) {
+            int32_t *pa = nullptr, *pb = nullptr;
+            MANY_TRY(hipHostMalloc(&pa, sizeof(int32_t) * (size_t)(n_cap + m_cap + 2)));
+            e->h_ai.push_back(pa);
+            MANY_TRY(hipHostMalloc(&pb, sizeof(int32_t) * (size_t)(n_cap + m_cap + 2)));
+            e->h_bj.push_back(pb);
+        }
+    }
+    // first use of the engine's stream now, not while fills of other engines are running (creating a
+    // hardware queue under resident fills was seen to stall them for seconds under a profiler)
+    MANY_TRY(hipMemsetAsync(e->ticket, 0, 256, e->stream));
+    MANY_TRY(hipStreamSynchronize(e->stream));
+#undef MANY_TRY
+    *out = e;
+    return PSA_OK;
+}
+
+int psa_many_set_pair(psa_many* e, int slot, const uint8_t* a, int64_t n, const uint8_t* b, int64_t m) {
+    if (e && e->launched) return fail(PSA_E_STATE, "psa_many_set_pair: results of the last launch have not been waited for");
+    if ((n > 0 && !a) || (m > 0 && !b)) return fail(PSA_E_ARG, "psa_many_set_pair: null sequence");
+    if (int rc = many_bind(e, slot, n, m)) return rc;
+    if (e->bound[slot] != 1) return PSA_OK;
+    DeviceGuard g(e->device);
+    if (g.rc) return g.rc;
+    return upload_host(e->st[slot], a, b, e->stream);
+}
+
+int psa_many_set_pair_dev(psa_many* e, int slot, const uint8_t* a_dev, int64_t n, const uint8_t* b_dev, int64_t m) {
+    if (e && e->launched) return fail(PSA_E_STATE, "psa_many_set_pair_dev: results of the last launch have not been waited for");
+    if ((n > 0 && !a_dev) || (m > 0 && !b_dev)) return fail(PSA_E_ARG, "psa_many_set_pair_dev: null sequence");
+    if (int rc = many_bind(e, slot, n, m)) return rc;
+    if (e->bound[slot] != 1) return PSA_OK;
+    DeviceGuard g(e->device);
+    if (g.rc) return g.rc;
+    psa_stripe* s = e->st[slot];
+    HIP_TRY(hipMemcpyAsync(s->a_dev, a_dev, (size_t)n, hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(s->b_dev, b_dev, (size_t)m, hipMemcpyDeviceToDevice, e->stream));
+    return rebuild_tables(s, e->stream, -1);
+}
+
+int psa_many_clear_slot(psa_many* e, int slot) {
+    if (!e || slot < 0 || slot >= e->slots) return fail(PSA_E_ARG, "psa_many_clear_slot: no such slot");
+    if (e->launched) return fail(PSA_E_STATE, "psa_many_clear_slot: results of the last launch have not been waited for");
+    e->bound[slot] = 0;
+    return PSA_OK;
+}
+
+// ONE fill launch over all bound slots, ONE launch of their walks, results copied to pinned host memory:
+// everything asynchronous on the engine's stream.
+int psa_many_launch(psa_many* e) {
+    if (!e) return fail(PSA_E_ARG, "psa_many_launch: null engine");
+    if (e->launched) return fail(PSA_E_STATE, "psa_many_launch: results of the last launch have not been waited for");
+    DeviceGuard g(e->device);
+    if (g.rc) return g.rc;
+    hipStream_t st = e->stream;
+    const bool with_codes = (e->flags & PSA_F_TRACEBACK) != 0;
+    psa::FillArgs2 jobs[psa::kMaxJobs];
+    int slot_of[psa::kMaxJobs];
+    unsigned groups[psa::kMaxJobs];
+    int nj = 0;
+    unsigned total = 0, rounds = 0;
+    HIP_TRY(hipEventRecord(e->ev[0], st));
+    for (int k = 0; k < e->slots; ++k) {
+        if (e->bound[k] != 1) continue;
+        psa_stripe* s = e->st[k];
+        if (!s->use_v2) {   // alphabets of more than 32 symbols: the generic kernel, a launch of its own
+            if (int rc = fill_rows_impl(s, 0, s->n, nullptr, nullptr, st, FillOpts())) return rc;
+            continue;
+        }
+        bool wc = false;
+        if (int rc = prepare_fill(s, 0, s->n, nullptr, nullptr, st, FillOpts(), &jobs[nj], &wc)) return rc;
+        groups[nj] = groups_of(jobs[nj]);
+        total += groups[nj];
+        rounds = std::max(rounds, groups[nj]);
+        slot_of[nj++] = k;
+    }
+    if (nj > 0) {
+        const uint32_t* order_dev = nullptr;
+        if (nj > 1) {   // round-robin over the jobs that still have groups left
+            std::vector<uint32_t> order;
+            order.reserve(total);
+            for (unsigned r = 0; r < rounds; ++r)
+                for (int j = 0; j < nj; ++j)
+                    if (r < groups[j]) order.push_back(((uint32_t)j << psa::kOrderJobShift) | r);
+            if (e->order_cap < order.size()) {
+                hipFree(e->order);
+                e->order = nullptr; e->order_cap = 0;
+                HIP_TRY(hipMalloc(&e->order, sizeof(uint32_t) * order.size()));
+                e->order_cap = order.size();
+            }
+            HIP_TRY(hipMemcpyAsync(e->order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));   // (the vector goes out of scope; the copy is a few KB)
+            order_dev = e->order;
+        }
+        HIP_TRY(hipMemsetAsync(e->ticket, 0, 256, st));
+        if (int rc = launch_fill_v2(jobs, nj, order_dev, total, e->ticket, with_codes,
+                                    nj > 1 ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes, st)) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->ev[1], st));
+    // the walks: one wavefront per pair, all in one launch, each starting from its pair's final pick
+    if (with_codes) {
+        psa::TraceBatch tb;
+        memset(&tb, 0, sizeof tb);
+        int nt = 0;
+        for (int k = 0; k < e->slots; ++k) {
+            if (e->bound[k] != 1) continue;
+            psa_stripe* s = e->st[k];
+            if (!walk_fits32(s, s->Q)) return fail(PSA_E_ARG, "psa_many: pair too large for the batched walk");
+            if (int rc = make_trace_args(s, TraceOpts(), &tb.job[nt])) return rc;
+            tb.job[nt].start_triple = s->small + kFinalWord;
+            ++nt;
+        }
+        tb.njobs = nt;
+        if (nt > 0) {
+            hipLaunchKernelGGL(psa::traceback_wave_many, dim3(nt), dim3(64), 0, st, tb);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(e->ev[2], st));
+    for (int k = 0; k < e->slots; ++k) {
+        if (e->bound[k] != 1) continue;
+        psa_stripe* s = e->st[k];
+        HIP_TRY(hipMemcpyAsync(e->h_triple + 4 * k, s->small + kFinalWord, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(e->h_abort + k, s->ctrl + kAbortWord, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        if (with_codes) {
+            HIP_TRY(hipMemcpyAsync(e->h_state + 16 * k, s->tb_state, sizeof(int64_t) * 12, hipMemcpyDeviceToHost, st));
+            const size_t cnt = (size_t)(s->n + s->W + 2);   // (the walk's length is not known on the host yet: all it can be)
+            HIP_TRY(hipMemcpyAsync(e->h_ai[k], s->tb_ai, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(e->h_bj[k], s->tb_bj, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+        }
+    }
+    HIP_TRY(hipEventRecord(e->ev[3], st));
+    e->launched = true;
+    return PSA_OK;
+}
+
+int psa_many_wait(psa_many* e) {
+    if (!e) return fail(PSA_E_ARG, "psa_many_wait: null engine");
+    if (!e->launched) return PSA_OK;
+    DeviceGuard g(e->device);
+    if (g.rc) return g.rc;
+    HIP_TRY(hipEventSynchronize(e->ev[3]));
+    e->launched = false;
+    return PSA_OK;
+}
+
+int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_out[3], int32_t* ai, int32_t* bj, int64_t cap,
+                    int64_t* len_out) {
+    if (!e || slot < 0 || slot >= e->slots || !score_out) return fail(PSA_E_ARG, "psa_many_result: bad argument");
+    if (e->launched) if (int rc = psa_many_wait(e)) return rc;
+    if (e->bound[slot] == 0) return fail(PSA_E_STATE, "psa_many_result: slot %d holds no pair", slot);
+    const int64_t n = e->n[slot], m = e->m[slot];
+    int32_t t[3];
+    if (n == 0) { t[0] = -1; t[1] = 0; t[2] = (int32_t)-(2 + m); }
+    else if (m == 0) { t[0] = -1; t[1] = (int32_t)-(2 + n); t[2] = -1; }
+    else {
+        if (e->h_abort[slot]) return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired (slot %d)", slot);
+        memcpy(t, e->h_triple + 4 * slot, sizeof t);
+    }
+    pick3(t, score_out);
+    if (triple_out) memcpy(triple_out, t, sizeof t);
+    if (!(e->flags & PSA_F_TRACEBACK) || !ai || !bj) { if (len_out) *len_out = 0; return PSA_OK; }
+    if (!len_out) return fail(PSA_E_ARG, "psa_many_result: len_out is null");
+    int64_t len = 0;
+    if (n > 0 && m > 0) {
+        const int64_t* stt = e->h_state + 16 * slot;
+        if (stt[5] == 2) return fail(PSA_E_KERNEL, "traceback: winner codes failed the decode check (slot %d)", slot);
+        if (stt[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow (slot %d)", slot);
+        if (!stt[3]) return fail(PSA_E_KERNEL, "traceback: the walk stopped before the matrix boundary (slot %d)", slot);
+        len = stt[4];
+        if (len + n + m > cap) return fail(PSA_E_ARG, "psa_many_result: output capacity %lld too small", (long long)cap);
+        memcpy(ai, e->h_ai[slot], sizeof(int32_t) * (size_t)len);
+        memcpy(bj, e->h_bj[slot], sizeof(int32_t) * (size_t)len);
+    }
+    return psa_finish_alignment(ai, bj, len, cap, len_out);
+}
+
+int psa_many_last_ms(psa_many* e, float* fill_ms_out, float* walk_ms_out) {
+    if (!e) return fail(PSA_E_ARG, "psa_many_last_ms: null engine");
+    if (e->launched) if (int rc = psa_many_wait(e)) return rc;
+    DeviceGuard g(e->device);
+    if (g.rc) return g.rc;
+    if (fill_ms_out) HIP_TRY(hipEventElapsedTime(fill_ms_out, e->ev[0], e->ev[1]));
+    if (walk_ms_out) HIP_TRY(hipEventElapsedTime(walk_ms_out, e->ev[1], e->ev[2]));
+    return PSA_OK;
+}
+
+int64_t psa_many_code_bytes(const psa_many* e, int slot) {
+    return (e && slot >= 0 && slot < e->slots && e->bound[slot] == 1) ? (int64_t)e->st[slot]->code_bytes : 0;
+}
+
+// run() in a loop (simple.cpp:311 called once per pair): the pairs go through two engines that take
+// turns, so that the walks and copies of one batch run beside the fill of the next.
+int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, const uint8_t* const* b, const int64_t* m,
+                   int32_t* scores_out, int32_t** ai_out, int32_t** bj_out, int64_t* len_out) {
+    if (npairs < 0 || (npairs && (!a || !n || !b || !m || !scores_out))) return fail(PSA_E_ARG, "psa_align_many: bad argument");
+    const bool want_al = ai_out && bj_out && len_out;
+    if (npairs == 0) return PSA_OK;
+    if (int rc = need_device()) return rc;
+    int64_t n_cap = 1, m_cap = 1;
+    for (int64_t k = 0; k < npairs; ++k) {
+        if (n[k] < 0 || m[k] < 0 || (n[k] && !a[k]) || (m[k] && !b[k])) return fail(PSA_E_ARG, "psa_align_many: pair %lld is malformed", (long long)k);
+        if (n[k] > (1LL << 27) || m[k] > (1LL << 27)) return fail(PSA_E_ARG, "sequence longer than 2^27 is not supported");
+        n_cap = std::max(n_cap, n[k]); m_cap = std::max(m_cap, m[k]);
+        if (want_al) { ai_out[k] = bj_out[k] = nullptr; len_out[k] = 0; }
+    }
+    // slots per engine: what fits in half of the free device memory, at most 4 (two engines: 8 pairs in flight)
+    psa_release_cache();
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    const double per_slot = (want_al ? (double)n_cap * (double)m_cap * 1.05 : 0.0) + 64.0 * (double)(n_cap + m_cap) + (1 << 20);
+    int slots = (int)std::min<double>(4.0, 0.5 * (double)free_b / (2.0 * per_slot));
+    slots = (int)std::min<int64_t>(slots, (npairs + 1) / 2);
+    if (slots < 1) {
+        // not even one pair per engine fits with its codes: one at a time through psa_align (linear space if need be)
+        for (int64_t k = 0; k < npairs; ++k) {
+            if (want_al) { if (int rc = psa_align(a[k], n[k], b[k], m[k], 1, &scores_out[k], &ai_out[k], &bj_out[k], &len_out[k])) return rc; }
+            else if (int rc = psa_score(a[k], n[k], b[k], m[k], 1, &scores_out[k], nullptr)) return rc;
+        }
+        return PSA_OK;
+    }
+    psa_many* eng[2] = {nullptr, nullptr};
+    std::vector<int64_t> held[2];
+    int rc = PSA_OK;
+    auto collect = [&](int x) -> int {
+        if (int r = psa_many_wait(eng[x])) return r;
+        for (size_t sl = 0; sl < held[x].size(); ++sl) {
+            const int64_t k = held[x][sl];
+            if (want_al) {
+                const int64_t cap = 2 * (n[k] + m[k]) + 2;
+                ai_out[k] = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+                bj_out[k] = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+                if (!ai_out[k] || !bj_out[k]) return fail(PSA_E_NOMEM, "psa_align_many: host allocation failed");
+                if (int r = psa_many_result(eng[x], (int)sl, &scores_out[k], nullptr, ai_out[k], bj_out[k], cap, &len_out[k])) return r;
+            } else if (int r = psa_many_result(eng[x], (int)sl, &scores_out[k], nullptr, nullptr, nullptr, 0, nullptr)) return r;
+        }
+        held[x].clear();
+        return PSA_OK;
+    };
+    for (int x = 0; x < 2 && rc == PSA_OK; ++x) rc = psa_many_create(&eng[x], slots, n_cap, m_cap, want_al ? PSA_F_TRACEBACK : 0);
+    int turn = 0;
+    for (int64_t k0 = 0; k0 < npairs && rc == PSA_OK; k0 += slots, turn ^= 1) {
+        if (!held[turn].empty()) rc = collect(turn);
+        for (int sl = 0; sl < slots && rc == PSA_OK; ++sl) {
+            const int64_t k = k0 + sl;
+            if (k < npairs) { rc = psa_many_set_pair(eng[turn], sl, a[k], n[k], b[k], m[k]); held[turn].push_back(k); }
+            else rc = psa_many_clear_slot(eng[turn], sl);
+        }
+        if (rc == PSA_OK) rc = psa_many_launch(eng[turn]);
+    }
+    for (int x = 0; x < 2 && rc == PSA_OK; ++x) if (!held[x].empty()) rc = collect(x);
+    for (int x = 0; x < 2; ++x) free_many(eng[x]);
+    if (rc != PSA_OK && want_al)
+        for (int64_t k = 0; k < npairs; ++k) { free(ai_out[k]); free(bj_out[k]); ai_out[k] = bj_out[k] = nullptr; }
+    return rc;
 }
 
 int psa_score_batch(const uint8_t* seqs, const int64_t* offsets, int64_t nseqs, const int32_t* pairs,
@@ -754,6 +1292,7 @@ int psa_score_batch_dev(const uint8_t* seqs_dev, const int64_t* offsets_dev, con
     HIP_TRY(hipGetLastError());
     return PSA_OK;
 }
+
 
 // simple.cpp:312 + output_alignement (simple.cpp:43-70); both Length lines print al_A's size.
 char* psa_format_result(int32_t score, const uint8_t* a, const uint8_t* b, const int32_t* ai, const int32_t* bj,

@@ -26,6 +26,9 @@ struct FillArgs {
     const int32_t* corner;   // [3] plain triple at (r0, c0) when left != null and r0 > 0
     int32_t* corner_next;    // [3] receives the triple at (r1, c0)
     int32_t* right;          // [3][R] plain triple at column c0+W, or null
+    const unsigned* left_done;  // stripes of one pair filled by ONE launch: left_done[strip] != 0 once the stripe on the
+    unsigned* right_done;       // left has stored that strip's rows of `left`; this stripe raises right_done[strip]
+                                // behind its stores to `right` (both null: boundaries cross a kernel boundary)
     int32_t* final_triple;   // [3] plain triple at (n, c0+W), written by the strip holding row n
     u64* ring;               // [2][Wpad] granules: bottom row of strip s lives in parity s&1
     uint8_t* codes;          // winner codes (one byte per cell, psa_device.hip.h) or null
@@ -213,6 +216,14 @@ struct TraceArgs {
     int64_t* state;          // in: i, j, k ; out: i, j, k, done (1 = reached the matrix boundary), len, error
     int64_t row_min;         // banded mode: the codes at hand cover rows > row_min only (0: whole matrix);
                              // `codes` then points row_min/64 strips before the band's first tile
+    int64_t n;               // rows of the whole matrix
+    const int32_t* start_triple;   // not null: the walk starts at (n, c0 + W) in the table the final pick of this
+                                   // triple names (simple.cpp:246-256) instead of at state[0..2]
+};
+constexpr int kMaxWalks = 8;
+struct TraceBatch {          // one wavefront (workgroup) per walk
+    TraceArgs job[kMaxWalks];
+    int njobs;
 };
 
 // The values the reference compared at a cell, modulo 16 (psa_device.hip.h, "winner codes"), for any cell
@@ -333,13 +344,19 @@ __device__ __forceinline__ void tb_wait_vm(int n_after) {
 #define PSA_LIKELY(x) __builtin_expect(!!(x), 1)
 #define PSA_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
-__global__ __launch_bounds__(64) void traceback_wave(TraceArgs p) {
+__device__ __forceinline__ void tb_walk(const TraceArgs& p) {
     __shared__ __attribute__((aligned(16))) uint8_t tiles[kTbSlots * kTbSlotBytes];
     const int lane = threadIdx.x;
     int i = __builtin_amdgcn_readfirstlane((int)p.state[0]);
     int j = __builtin_amdgcn_readfirstlane((int)p.state[1]);
     int k = __builtin_amdgcn_readfirstlane((int)p.state[2]);
     const int c0 = (int)p.c0;
+    if (p.start_triple) {
+        const int t1 = __builtin_amdgcn_readfirstlane(p.start_triple[0]), t2 = __builtin_amdgcn_readfirstlane(p.start_triple[1]),
+                  t3 = __builtin_amdgcn_readfirstlane(p.start_triple[2]);
+        i = (int)p.n; j = c0 + p.W;
+        k = (t1 >= t2 && t1 >= t3) ? 1 : (t2 >= t3 ? 2 : 3);
+    }
     const int Q = p.Q;
     const int rmin = (int)p.row_min;
     const int cap = (int)(p.cap < 0x1fffff00 ? p.cap : 0x1fffff00);   // 4 * cap fits the buffer descriptor
@@ -607,6 +624,14 @@ __global__ __launch_bounds__(64) void traceback_wave(TraceArgs p) {
         p.state[10] = (tsec[0] << 32) | (tsec[1] & 0xffffffffLL); p.state[11] = (tsec[2] << 32) | (tsec[3] & 0xffffffffLL);
 #endif
     }
+}
+
+__global__ __launch_bounds__(64) void traceback_wave(TraceArgs p) { tb_walk(p); }
+
+// several walks in one launch: workgroup w walks job w
+__global__ __launch_bounds__(64) void traceback_wave_many(TraceBatch B) {
+    const TraceArgs p = B.job[blockIdx.x];
+    tb_walk(p);
 }
 
 }  // namespace psa

@@ -253,3 +253,68 @@ def test_banded_generic_kernels_and_tiny():
         res = psa_amd.align(x, y, 1, band_rows=256)
         sc, ai, bj = O.align(x, y)
         assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (x.size, y.size)
+
+
+def test_align_many_matches_oracle():
+    """psa_align_many (run() in a loop, simple.cpp:311; batches of pairs filled by ONE launch and walked by ONE
+    launch): different sizes in one batch, pairs without cells, an alphabet the table kernel does not take."""
+    rng = np.random.default_rng(31)
+    pairs = []
+    for n, m, alpha in ((700, 650, 4), (64, 64, 2), (1, 300, 3), (300, 1, 3), (1500, 2100, 20), (257, 255, 4),
+                        (0, 10, 4), (10, 0, 4), (0, 0, 4), (1000, 1000, 4), (333, 4000, 20), (2048, 2048, 20),
+                        (129, 4097, 2)):
+        pairs.append((rng.integers(65, 65 + alpha, n).astype(np.uint8), rng.integers(65, 65 + alpha, m).astype(np.uint8)))
+    pairs.append((rng.integers(40, 100, 500).astype(np.uint8), rng.integers(40, 100, 444).astype(np.uint8)))   # 60 symbols
+    x = rng.integers(65, 69, 3000).astype(np.uint8)
+    pairs.append((x, np.concatenate([x[:1000], x[1400:]])))
+    got = psa_amd.align_many(pairs)
+    for (a, b), res in zip(pairs, got):
+        sc, ai, bj = O.align(a, b)
+        assert res.score == sc, (a.size, b.size)
+        assert np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (a.size, b.size)
+    scores = psa_amd.align_many(pairs, alignments=False)
+    assert [r.score for r in scores] == [r.score for r in got]
+
+
+def test_many_engine_reuse_and_device_inputs():
+    """The engine itself: slots re-bound to pairs of other sizes between launches, residues taken from device memory."""
+    import torch
+    rng = np.random.default_rng(32)
+    eng = psa_amd.Many(3, 3000, 3500)
+    for rnd in range(3):
+        batch = []
+        for sl in range(3 if rnd != 1 else 2):
+            n, m = int(rng.integers(1, 3000)), int(rng.integers(1, 3500))
+            a = rng.integers(65, 69, n).astype(np.uint8)
+            b = np.where(rng.random(m) < 0.6, np.resize(a, m), rng.integers(65, 69, m)).astype(np.uint8)
+            batch.append((a, b))
+            if rnd == 2:
+                ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+                torch.cuda.synchronize()
+                eng.set_pair_dev(sl, ta.data_ptr(), n, tb.data_ptr(), m)
+                batch[-1] = (a, b, ta, tb)
+            else:
+                eng.set_pair(sl, a, b)
+        if rnd == 1:
+            eng.clear_slot(2)
+        eng.launch()
+        eng.wait()
+        for sl, item in enumerate(batch):
+            a, b = item[0], item[1]
+            res = eng.result(sl, a.size, b.size)
+            sc, ai, bj = O.align(a, b)
+            assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (rnd, sl)
+    eng.close()
+
+
+def test_stripes_in_one_launch_at_size():
+    """p stripes of one pair are jobs of ONE launch (flags between them): same score and alignment as p = 1 at a
+    size where the stripes really overlap in time, and p > 8 (several launches of up to 8 stripes)."""
+    a = psa_amd.synth_protein(0xA0000000 + 13, 1 << 13)
+    b = psa_amd.synth_protein(0xB0000000 + 13, 1 << 13)
+    ref = psa_amd.align(a, b, 1)
+    assert ref.score == O.score(a, b, 8)
+    for p in (2, 4, 8, 11):
+        res = psa_amd.align(a, b, p)
+        assert res.score == ref.score and np.array_equal(res.ai, ref.ai) and np.array_equal(res.bj, ref.bj), p
+        assert psa_amd.score(a, b, p) == ref.score
