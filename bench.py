@@ -3,35 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete alignment of the workload pair: DP fill with packed winner codes
-written to HBM, final pick, traceback walk, prefix fix-up (what run() does in simple.cpp:261-294).
-Inputs are resident in HBM before the timed region.  N = 1: the synthetic 2^16 x 2^16 protein
-pair of BASELINE config 4 on one GPU.  N > 1 (launched by torch.distributed.run, one rank per
-GPU): every rank does the same with its own pairs, no data-path communication (weak scaling; the
-"batched many-pair" sharding of the north star); --mode stripes instead cuts ONE pair into N
-column stripes, boundary columns streamed g -> g+1 with RCCL send/recv (bench_multi.py; its
-dependency chain is n + m steps long on any number of GPUs, so it buys capacity, not time, at
-2^16).  One pair alone cannot fill the GPU (its anti-diagonal
-dependency chain is n + m steps long whatever the hardware), so the job keeps --in-flight
-(default 6) independent alignments going at a time, each on its own stream with its own code
-buffer; "value" is the job's throughput, "one_pair_alone" the latency of a single alignment, and
-the roofline object is the fill kernel measured alone.  Rank 0 prints ONE JSON line.
+One "step" = one complete alignment of the workload pair: DP fill with winner codes written to HBM,
+final pick, traceback walk, prefix fix-up (what run() does in simple.cpp:261-294).  Inputs are
+resident in HBM before the timed region.  N = 1: the synthetic 2^16 x 2^16 protein pair of BASELINE
+config 4 on one GPU.  One pair alone cannot fill the GPU (its anti-diagonal dependency chain is
+n + m steps long whatever the hardware), so the job is what psa_align_many does: ONE host thread
+drives two psa_many engines that take turns; every batch of --slots pairs is ONE fill launch (the
+pairs' strips interleaved) and ONE launch of their walks, and the walks and copies of one batch run
+beside the fill of the next.  "value" is the job's throughput, "one_pair_alone" the latency of a
+single alignment, and the roofline object is the dominant kernel -- the fill launch -- timed live
+with HIP events on the engine's stream inside the timed region.
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank does the same with its own
+pairs, no data-path communication (weak scaling; the "batched many-pair" sharding of the north star);
+the same line then also carries the strong-scaling figures of ONE pair cut into N column stripes
+(boundary columns streamed g -> g+1 with RCCL send/recv) under "stripes".  Rank 0 prints ONE JSON line.
 
 Extra keys beside the contract: roofline (int32 VALU), cpu_baseline (the oracle's
 multi-threaded port timed on host cores, rank 0, N = 1 only), and secondary measurements
-(score-only fill, titin pair) under "extra".
+(score-only fill, titin pair, batch kernel) under "extra".
 """
 import argparse
 import json
 import os
 import sys
 import time
-
-# Every alignment in flight has a stream of its own; with HIP's default of 4 hardware queues per process
-# streams share queues, and one stream's small kernels wait behind another stream's fill.
-_HWQ = min(32, int(os.environ.get("PSA_BENCH_HW_QUEUES", "8")))
-if int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < _HWQ:
-    os.environ["GPU_MAX_HW_QUEUES"] = str(_HWQ)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -41,21 +36,24 @@ VALU_PEAK_TOPS = 39.3216      # 256 CU x 64 int32 lanes/clk x 2.4 GHz (tools/val
 OPS_PER_CELL_CODES = 25       # algorithmic int32 VALU ops per cell with winner codes
 OPS_PER_CELL_SCORE = 10       # score only
 HBM_PEAK_GBS = 8000.0
+PROFILE_DIR = os.path.join("profiles", "r2")
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
-    ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1)")
-    ap.add_argument("--in-flight", type=int, default=6,
-                    help="independent alignments in flight per GPU (at most 8: one hardware queue each)")
+    ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1, stripes)")
+    ap.add_argument("--slots", type=int, default=8, help="pairs per launch (1..8); two engines take turns")
+    ap.add_argument("--overlap-fills", action="store_true",
+                    help="let the two engines' fill launches overlap (default: each fill launch alone on the chip)")
     ap.add_argument("--mode", choices=["pairs", "stripes"], default="pairs",
-                    help="N > 1: independent pairs per GPU (default) or one pair in N column stripes")
+                    help="N > 1: independent pairs per GPU plus the stripes figures (default), or only the stripes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-stripes", action="store_true", help="N > 1: skip the strong-scaling stripes figures")
     return ap.parse_args()
 
 
@@ -73,138 +71,139 @@ def cpu_baseline(a, b, log2s=16):
             "score": int(sc)}
 
 
+def pmc_rows(name):
+    import csv
+    path = os.path.join(ROOT, PROFILE_DIR, name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return list(csv.DictReader(f))
+
+
 def pmc_traffic(kernel_substr, grid):
     """HBM bytes per launch of the fill kernel from the committed rocprofv3 --pmc passes (WRITE_SIZE and
     FETCH_SIZE, one pass each, summarised by tools/rocpd_summary.py into profiles/).  FETCH_SIZE is doubled
     (gfx950 correction, MI355X_MICROARCH.md, HBM section).  None when the summaries are absent."""
-    import csv
     tot, src = 0.0, []
-    for name, scale in (("pmc_w_bench_2p16.csv", 1024.0), ("pmc_f_bench_2p16.csv", 2048.0)):
-        path = os.path.join(ROOT, "profiles", "r1", name)
-        if not os.path.exists(path):
+    for name, scale in (("pmc_w_bench.csv", 1024.0), ("pmc_f_bench.csv", 2048.0)):
+        rows = pmc_rows(name)
+        if rows is None:
             return None, None
         hit = False
-        with open(path) as f:
-            for row in csv.DictReader(f):
-                if kernel_substr in row["kernel"] and int(row["grid_size"]) == grid and row["counter"] in ("WRITE_SIZE", "FETCH_SIZE"):
-                    tot += float(row["avg_value"]) * scale
-                    hit = True
+        for row in rows:
+            if kernel_substr in row["kernel"] and int(row["grid_size"]) == grid and row["counter"] in ("WRITE_SIZE", "FETCH_SIZE"):
+                tot += float(row["avg_value"]) * scale
+                hit = True
         if not hit:
             return None, None
-        src.append("profiles/r1/" + name)
+        src.append(PROFILE_DIR + "/" + name)
     return tot, src
 
 
 def pmc_valu_per_cell(kernel_substr, grid, cells):
     """Executed VALU instructions per cell (SQ_INSTS_VALU x 64 lanes / cells) from the committed --pmc pass."""
-    import csv
-    path = os.path.join(ROOT, "profiles", "r1", "pmc_sq_bench_2p16.csv")
-    if not os.path.exists(path):
+    rows = pmc_rows("pmc_sq_bench.csv")
+    if rows is None:
         return None
-    with open(path) as f:
-        for row in csv.DictReader(f):
-            if kernel_substr in row["kernel"] and int(row["grid_size"]) == grid and row["counter"] == "SQ_INSTS_VALU":
-                return float(row["avg_value"]) * 64.0 / cells
+    for row in rows:
+        if kernel_substr in row["kernel"] and int(row["grid_size"]) == grid and row["counter"] == "SQ_INSTS_VALU":
+            return float(row["avg_value"]) * 64.0 / cells
     return None
 
 
+def init_dist(local):
+    """torch.distributed for N > 1: RCCL ("nccl") if it comes up, else gloo (rehearsals on one GPU)."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("PSA_BENCH_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend == "nccl":
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            probe = torch.zeros(1, device="cuda")
+            dist.all_reduce(probe)          # the first collective builds the communicator: fail here, not mid-run
+            torch.cuda.synchronize()
+        except Exception as e:              # the timing barrier is all the pairs mode needs: fall back to gloo
+            print("bench: nccl unavailable (%s), falling back to gloo" % e, file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            backend = "gloo"
+    if backend != "nccl":
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist, backend
+
+
+def throughput_job(psa_amd, engines, a_dev, b_dev, n, m, count, serial_fills):
+    """`count` complete alignments through two engines that take turns, ONE host thread.  Returns
+    (results, fill launch durations [(ms, pairs)], walk launch durations)."""
+    S = engines[0].slots
+    res, fills, walks = [], [], []
+    held = [0, 0]
+
+    def collect(x):
+        eng = engines[x]
+        eng.wait()
+        for sl in range(held[x]):
+            r = eng.result(sl, n, m)
+            res.append((r.score, len(r.ai)))
+        f, w = eng.last_ms()
+        fills.append((f, held[x])); walks.append(w)
+        held[x] = 0
+
+    turn, left = 0, count
+    while left > 0:
+        eng = engines[turn]
+        if held[turn]:
+            collect(turn)
+        take = min(S, left)
+        for sl in range(S):
+            if sl < take:
+                eng.set_pair_dev(sl, a_dev.data_ptr(), n, b_dev.data_ptr(), m)
+            else:
+                eng.clear_slot(sl)
+        eng.launch(engines[turn ^ 1] if serial_fills else None)
+        held[turn] = take
+        left -= take
+        turn ^= 1
+    for x in (turn, turn ^ 1):
+        if held[x]:
+            collect(x)
+    return res, fills, walks
+
+
 def single_gpu(args):
-    import threading
     import numpy as np
     import torch
     import psa_amd
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
-    backend = os.environ.get("PSA_BENCH_BACKEND", "nccl")   # gloo: rehearsal of the N > 1 logic on one GPU
     torch.cuda.set_device(local)
     psa_amd.set_device(local)
-    dist = None
+    dist, backend = (None, None)
     if world > 1:
-        # independent alignments per rank: no data-path communication, only the timing barrier
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-                probe = torch.zeros(1, device="cuda")
-                dist.all_reduce(probe)          # the first collective builds the communicator: fail here, not mid-run
-                torch.cuda.synchronize()
-            except Exception as e:              # the barrier is all this mode needs: fall back to gloo
-                print("bench: nccl unavailable (%s), timing barrier over gloo" % e, file=sys.stderr)
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = "gloo"
-        if backend != "nccl":
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        dist, backend = init_dist(local)
     k = args.log2n
     n = m = 1 << k
     a = psa_amd.synth_protein(0xA0000000 + k, n)
     b = psa_amd.synth_protein(0xB0000000 + k, m)
     a_dev = torch.from_numpy(a).cuda()
     b_dev = torch.from_numpy(b).cuda()
-    # more streams than hardware queues makes the GPU's scheduler time-slice the queues, and a fill that
-    # is switched out with its 96 KB of LDS per workgroup takes seconds (measured: 10 in flight = 1 s each)
-    P = min(8, max(1, args.in_flight))
-    stripes = [psa_amd.Stripe(a, b, 0, m, traceback=True) for _ in range(P)]
-    streams = [torch.cuda.Stream() for _ in range(P)]
-    cap = 2 * (n + m) + 2
-
-    def one_alignment(st, stream, ai, bj):
-        """run() of the reference for one pair whose residues are already in HBM."""
-        st.set_sequences_dev(a_dev.data_ptr(), b_dev.data_ptr(), stream)
-        st.fill_rows(0, n, None, None, stream)
-        t = st.final(stream)
-        kk, sc = psa_amd.pick(*t)
-        _, _, _, ln = st.traceback(n, m, kk, ai, bj, 0, stream)
-        fa, fb = psa_amd.finish_alignment(ai[:ln], bj[:ln], n, m)
-        return sc, len(fa)
-
-    def run_steps(count, stagger_s=0.0):
-        """`count` independent alignments, up to P of them in flight: one host thread, stripe object and
-        stream per slot; a slot takes the next alignment as soon as it has finished its last one.  Slot i
-        starts i * stagger_s late, so that the slots do not march in step (all filling, then all walking)."""
-        lock = threading.Lock()
-        state = {"next": 0}
-        res, fill_ms, tb_ms = [], [], []
-
-        def worker(slot):
-            torch.cuda.set_device(local)   # (the current device is per thread; the library also switches to the stripe's)
-            psa_amd.set_device(local)
-            st, stream = stripes[slot], streams[slot].cuda_stream
-            ai = np.zeros(cap, np.int32)
-            bj = np.zeros(cap, np.int32)
-            if slot and stagger_s > 0:
-                time.sleep(slot * stagger_s)
-            while True:
-                with lock:
-                    if state["next"] >= count:
-                        return
-                    state["next"] += 1
-                r = one_alignment(st, stream, ai, bj)
-                with lock:
-                    res.append(r); fill_ms.append(st.last_fill_ms()); tb_ms.append(st.last_traceback_ms())
-
-        th = [threading.Thread(target=worker, args=(i,)) for i in range(min(P, max(count, 1)))]
-        [x.start() for x in th]
-        [x.join() for x in th]
-        return res, fill_ms, tb_ms
-
-    # first use of every slot's stream on its own: creating a hardware queue (and, under rocprofv3, its
-    # interception) while fills of other slots are running was seen to freeze those fills for seconds
-    _ai = np.zeros(cap, np.int32); _bj = np.zeros(cap, np.int32)
-    for st_, sm_ in zip(stripes, streams):
-        one_alignment(st_, sm_.cuda_stream, _ai, _bj)
     torch.cuda.synchronize()
-    run_steps(args.warmup, 0.004)
+    S = min(8, max(1, args.slots))
+    engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(2)]
+    serial = not args.overlap_fills
+
+    throughput_job(psa_amd, engines, a_dev, b_dev, n, m, args.warmup, serial)
     torch.cuda.synchronize()
-    stagger = 0.004
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res, fill_ovl, tb_ovl = run_steps(args.steps, stagger)
+    res, fills, walks = throughput_job(psa_amd, engines, a_dev, b_dev, n, m, args.steps, serial)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -216,71 +215,84 @@ def single_gpu(args):
         dt = float(dtt.item())
     assert len(res) == args.steps and len(set(res)) == 1, res
     sc, ln = res[0]
-    cells = float(n) * m * world          # per step: one alignment on every rank
+    cells1 = float(n) * m
+    cells = cells1 * world                # per step: one alignment on every rank
     ms_step = dt / args.steps * 1e3
+    code_bytes = engines[0].code_bytes(0)
+    for e in engines:
+        e.close()
+
+    stripes_info = None
+    if dist and not args.no_stripes:
+        stripes_info = stripes_figures(args, dist, backend, local)
     if rank != 0:
-        for s_ in stripes:
-            s_.close()
         dist.barrier()                    # rank 0 is still measuring; leave together
         dist.destroy_process_group()
         return None
 
-    # the same alignment alone on the GPU: latency of one pair, and the fill kernel's own duration
-    st = stripes[0]
-    ai0 = np.zeros(cap, np.int32); bj0 = np.zeros(cap, np.int32)
-    fill_ms, tb_ms = [], []
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    iso_reps = 3
-    for _ in range(iso_reps):
-        r = one_alignment(st, streams[0].cuda_stream, ai0, bj0)
-        assert r == (sc, ln)
-        fill_ms.append(st.last_fill_ms()); tb_ms.append(st.last_traceback_ms())
-    torch.cuda.synchronize()
-    lat_ms = (time.perf_counter() - t1) / iso_reps * 1e3
-    fill = sum(fill_ms) / len(fill_ms)
-    fill_o = sum(fill_ovl) / len(fill_ovl)
-    cells1 = float(n) * m
-    achieved = cells1 * OPS_PER_CELL_CODES / (fill * 1e-3) / 1e12
-    aggregate = cells * OPS_PER_CELL_CODES * args.steps / dt / 1e12 / world   # per GPU
-    code_bytes = st.code_bytes()
-    traffic, traffic_src = pmc_traffic("fill_strips_v2<true>", 65536) if k == 16 else (None, None)
+    # ---- the dominant kernel: the fill launch over S pairs, HIP events on the engine's stream, timed region ----
+    full = [f for f, cnt in fills if cnt == S] or [f for f, cnt in fills]
+    per_launch_pairs = S if any(cnt == S for _, cnt in fills) else fills[0][1]
+    fill_ms = sum(full) / len(full)
+    achieved = per_launch_pairs * cells1 * OPS_PER_CELL_CODES / (fill_ms * 1e-3) / 1e12
+    aggregate = cells1 * OPS_PER_CELL_CODES * args.steps / dt / 1e12
+    grid = per_launch_pairs * ((n + 255) // 256)
+    traffic, traffic_src = pmc_traffic("fill_strips_v2<true>", grid * 256)
+
+    # ---- the same alignment alone on the GPU: latency of one pair, and the one-pair fill kernel ----
+    one = psa_amd.Many(1, n, m, traceback=True)
+    lat, f1, w1 = [], [], []
+    for rep in range(4):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one.set_pair_dev(0, a_dev.data_ptr(), n, b_dev.data_ptr(), m)
+        one.launch()
+        r = one.result(0, n, m)
+        lat.append((time.perf_counter() - t1) * 1e3)
+        assert (r.score, len(r.ai)) == (sc, ln)
+        f, w = one.last_ms()
+        f1.append(f); w1.append(w)
+    one.close()
+    lat_ms, fill1, walk1 = min(lat[1:]), sum(f1[1:]) / 3, sum(w1[1:]) / 3
     out = {
         "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of 2^%d x 2^%d pairs" % (k, k),
         "value": cells / (dt / args.steps) / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "synthetic iid 20-letter protein pair 2^%d x 2^%d (mt19937_64 seeds 0xA/0xB0000000+%d), "
-                               "fill with packed winner codes in HBM + traceback walk + prefix fix-up; one step = one "
-                               "complete alignment per GPU, up to %d independent alignments in flight on each (a "
-                               "stream and a code buffer each); no inter-GPU communication" % (k, k, k, P),
-                   "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1, "in_flight": P,
+                               "fill with one-byte winner codes in HBM + traceback walk + prefix fix-up; one step = one "
+                               "complete alignment per GPU; ONE host thread, two engines taking turns, %d pairs per "
+                               "fill launch and per walk launch (psa_many / psa_align_many); no inter-GPU "
+                               "communication" % (k, k, k, S),
+                   "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1, "pairs_per_launch": S,
+                   "fill_launches_overlap": bool(args.overlap_fills), "host_threads": 1,
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
-        "roofline": {"bound": "valu", "kernel": "fill_strips_v2<true> (fill with winner codes)", "achieved": achieved,
-                     "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
-                     "ops_per_cell": OPS_PER_CELL_CODES,
-                     "valu_insts_per_cell_executed": pmc_valu_per_cell("fill_strips_v2<true>", 65536, cells1) if k == 16 else None,
-                     "kernel_ms": fill,
-                     "kernel_ms_note": "HIP events around the launch, alignment alone on the GPU (%d launches after the "
-                                       "timed region); launches of the timed region overlap each other" % iso_reps,
-                     "launch_ms_overlapped": fill_o, "fill_gcups": cells1 / (fill * 1e-3) / 1e9,
+        "roofline": {"bound": "valu", "kernel": "fill_strips_v2<true>: ONE launch filling %d pairs (winner codes on)" % per_launch_pairs,
+                     "achieved": achieved, "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
+                     "ops_per_cell": OPS_PER_CELL_CODES, "cells_per_launch": per_launch_pairs * cells1,
+                     "valu_insts_per_cell_executed": pmc_valu_per_cell("fill_strips_v2<true>", grid * 256, per_launch_pairs * cells1),
+                     "kernel_ms": fill_ms, "launches_timed": len(full),
+                     "kernel_ms_note": "HIP events around the fill launch on the engine's stream, every launch of the timed "
+                                       "region; the other engine's walks (one wavefront per pair) run beside it",
+                     "fill_gcups": per_launch_pairs * cells1 / (fill_ms * 1e-3) / 1e9,
                      "aggregate_achieved": aggregate, "aggregate_frac": aggregate / VALU_PEAK_TOPS,
-                     "structural_ceiling_one_pair": min(1.0, cells1 / ((n + m) * 65536.0)),
+                     "one_pair_alone": {"kernel_ms": fill1, "frac": cells1 * OPS_PER_CELL_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                        "structural_ceiling": min(1.0, cells1 / ((n + m) * 65536.0))},
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (separate --pmc passes)",
                      "traffic_source": traffic_src,
-                     "code_stream": {"bytes": code_bytes, "GBps": code_bytes / (fill * 1e-3) / 1e9,
-                                     "frac_of_hbm_peak": code_bytes / (fill * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-        "one_pair_alone": {"ms": lat_ms, "gcups": cells1 / (lat_ms * 1e-3) / 1e9, "fill_ms": fill,
-                           "traceback_ms": sum(tb_ms) / len(tb_ms)},
-        "traceback_ms": sum(tb_ms) / len(tb_ms),
+                     "code_stream": {"bytes_per_launch": code_bytes * per_launch_pairs,
+                                     "GBps": code_bytes * per_launch_pairs / (fill_ms * 1e-3) / 1e9,
+                                     "frac_of_hbm_peak": code_bytes * per_launch_pairs / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        "one_pair_alone": {"ms": lat_ms, "gcups": cells1 / (lat_ms * 1e-3) / 1e9, "fill_ms": fill1, "traceback_ms": walk1},
+        "traceback_ms": sum(walks) / len(walks),
     }
-    for s_ in stripes[1:]:
-        s_.close()
-    stream = streams[0].cuda_stream
-    st.close()
+    if stripes_info is not None:
+        out["stripes"] = stripes_info
     extra = {}
     if not args.no_extra:
-        # score-only fill of the same pair
+        stream = torch.cuda.current_stream().cuda_stream
+        # score-only fill of the same pair, alone
         so = psa_amd.Stripe(a, b, 0, m, traceback=False)
         for _ in range(2):
             so.fill_rows(0, n, None, None, stream)
@@ -293,19 +305,7 @@ def single_gpu(args):
         ms = sum(ts) / len(ts)
         extra["score_only_2p%d" % k] = {"gcups": cells1 / (ms * 1e-3) / 1e9, "kernel_ms": ms, "score": int(max(t)),
                                         "valu_frac": cells1 * OPS_PER_CELL_SCORE / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
-        # titin pair (BASELINE config 3), full alignment
-        seqdir = os.path.join(ROOT, "tests", "golden", "sequences")
-        ta = psa_amd.read_fasta(os.path.join(seqdir, "titin_homo(50).fasta"))
-        tb = psa_amd.read_fasta(os.path.join(seqdir, "titin_mus.fasta"))
-        psa_amd.align(ta, tb, 1)
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            res = psa_amd.align(ta, tb, 1)
-        dtt = (time.perf_counter() - t0) / reps
-        extra["titin_pair"] = {"gcups_end_to_end_host_buffers": len(ta) * len(tb) / dtt / 1e9, "ms": dtt * 1e3,
-                               "score": int(res.score), "alignment_len": int(len(res.ai)),
-                               "note": "psa_align from host buffers: includes allocation, H2D and D2H"}
+        extra["titin_pair"] = titin_figures(psa_amd, torch, np)
         # BASELINE config 5 shape: a block of 512-residue proteins, all queries x all targets, score only
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_batch
@@ -321,11 +321,88 @@ def single_gpu(args):
     return out
 
 
+def titin_figures(psa_amd, torch, np):
+    """The titin pair (BASELINE config 3): device-resident fill + traceback through the stripe API, and the
+    end-to-end time of psa_align from host buffers (second call onwards: the thread's stripe objects are reused)."""
+    seqdir = os.path.join(ROOT, "tests", "golden", "sequences")
+    ta = np.frombuffer(psa_amd.read_fasta(os.path.join(seqdir, "titin_homo(50).fasta")), np.uint8)
+    tb = np.frombuffer(psa_amd.read_fasta(os.path.join(seqdir, "titin_mus.fasta")), np.uint8)
+    tn, tm = len(ta), len(tb)
+    cells = float(tn) * tm
+    stream = torch.cuda.current_stream().cuda_stream
+    st = psa_amd.Stripe(ta, tb, 0, tm, traceback=True)
+    ai = np.zeros(2 * (tn + tm) + 2, np.int32); bj = np.zeros(2 * (tn + tm) + 2, np.int32)
+    fm, wm = [], []
+    for rep in range(4):
+        st.fill_rows(0, tn, None, None, stream)
+        t = st.final(stream)
+        kk, sc = psa_amd.pick(*t)
+        _, _, _, ln = st.traceback(tn, tm, kk, ai, bj, 0, stream)
+        fm.append(st.last_fill_ms()); wm.append(st.last_traceback_ms())
+    st.close()
+    fill, walk = sum(fm[1:]) / 3, sum(wm[1:]) / 3
+    psa_amd.align(ta, tb, 1)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        res = psa_amd.align(ta, tb, 1)
+    dtt = (time.perf_counter() - t0) / reps
+    psa_amd.release_cache()
+    return {"n": tn, "m": tm, "score": int(res.score), "alignment_len": int(len(res.ai)),
+            "device_resident": {"fill_ms": fill, "traceback_ms": walk, "gcups_fill": cells / (fill * 1e-3) / 1e9,
+                                "gcups_fill_plus_traceback": cells / ((fill + walk) * 1e-3) / 1e9,
+                                "valu_frac_fill": cells * OPS_PER_CELL_CODES / (fill * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                "structural_ceiling": min(1.0, cells / ((tn + tm) * 65536.0))},
+            "gcups_end_to_end_host_buffers": cells / dtt / 1e9, "ms_end_to_end_host_buffers": dtt * 1e3,
+            "note": "host-buffer figure: psa_align incl. H2D, table build, D2H and prefix fix-up (stripe objects reused)"}
+
+
+def stripes_figures(args, dist, backend, local):
+    """Strong scaling of ONE pair cut into world_size column stripes (BASELINE config 4): 2^16 x 2^16 full
+    alignment and 2^20 x 2^20 score only, boundary columns streamed rank g -> g+1 (RCCL when the backend is nccl)."""
+    import importlib
+    import numpy as np
+    import torch
+    import psa_amd
+    D = importlib.import_module("parallel-sequence-alignment_amd.distributed")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    info = {"backend": backend, "chunk_rows": args.chunk_rows}
+    try:
+        ranks = [torch.zeros(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu") for _ in range(world)]
+        dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64, device=ranks[0].device))
+        info["rccl_ranks" if backend == "nccl" else "gloo_ranks"] = sorted(int(x.item()) for x in ranks)
+        for k, tb, reps in ((args.log2n, True, 3), (int(os.environ.get("PSA_BENCH_STRIPES_LOG2N", "20")), False, 1)):
+            n = m = 1 << k
+            a = psa_amd.synth_protein(0xA0000000 + k, n)
+            b = psa_amd.synth_protein(0xB0000000 + k, m)
+            c0, c1 = D.stripe_bounds(m, world, rank)
+            eng = D.HipStripeEngine(a, b, c0, c1, traceback=tb)
+            D.align_striped(a, b, chunk_rows=args.chunk_rows, traceback=tb, keep_engine=eng)   # warm-up
+            dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                res = D.align_striped(a, b, chunk_rows=args.chunk_rows, traceback=tb, keep_engine=eng)
+            dist.barrier(); torch.cuda.synchronize()
+            dtt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64,
+                               device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(dtt, op=dist.ReduceOp.MAX)
+            eng.close()
+            sec = float(dtt.item())
+            ops = OPS_PER_CELL_CODES if tb else OPS_PER_CELL_SCORE
+            info["2p%d_%s" % (k, "full_alignment" if tb else "score_only")] = {
+                "ms": sec * 1e3, "gcups": float(n) * m / sec / 1e9, "score": int(res.score), "stripes": world, "scaling": "strong",
+                "valu_frac_of_all_gpus": float(n) * m * ops / sec / 1e12 / (VALU_PEAK_TOPS * world),
+                "structural_ceiling": min(1.0, float(n) * m / ((n + m) * 65536.0 * world))}
+    except Exception as e:   # the replica figure must not be lost to the stripes leg
+        info["error"] = "%s: %s" % (type(e).__name__, e)
+    return info
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if (args.gpus > 1 or world > 1) and args.mode == "stripes":
-        from bench_multi import multi_gpu   # one pair cut into column stripes (strong scaling)
+        from bench_multi import multi_gpu   # one pair cut into column stripes (strong scaling) only
         out = multi_gpu(args)
     else:
         out = single_gpu(args)              # independent alignments on every GPU (weak scaling)

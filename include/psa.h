@@ -111,6 +111,9 @@ int psa_many_set_pair_dev(psa_many* e, int slot, const uint8_t* a_dev, int64_t n
                           int64_t m);
 int psa_many_clear_slot(psa_many* e, int slot);
 int psa_many_launch(psa_many* e);
+/* The same, but this engine's fill starts only when `after`'s fill launch has ended (NULL: at once):
+ * two engines taking turns then keep every fill launch alone on the chip, beside the other's walks. */
+int psa_many_launch_after(psa_many* e, psa_many* after);
 int psa_many_wait(psa_many* e);
 int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_out[3], int32_t* ai,
                     int32_t* bj, int64_t cap, int64_t* len_out);

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "psa_many_set_pair_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "psa_many_clear_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "psa_many_launch": (C.c_int, [C.c_void_p]),
+    "psa_many_launch_after": (C.c_int, [C.c_void_p, C.c_void_p]),
     "psa_many_wait": (C.c_int, [C.c_void_p]),
     "psa_many_result": (C.c_int, [C.c_void_p, C.c_int, _i32p, _i32p, C.c_void_p, C.c_void_p, _i64, _i64p]),
     "psa_many_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
@@ -286,8 +287,9 @@ class Many:
     def clear_slot(self, slot):
         _check(lib().psa_many_clear_slot(self._h, slot))
 
-    def launch(self):
-        _check(lib().psa_many_launch(self._h))
+    def launch(self, after=None):
+        """after: another Many whose fill launch must have ended before this one's begins."""
+        _check(lib().psa_many_launch_after(self._h, after._h if after is not None else None))
 
     def wait(self):
         _check(lib().psa_many_wait(self._h))

@@ -891,6 +891,7 @@ struct psa_many {
     unsigned* ticket = nullptr;     // 256 bytes
     uint32_t* order = nullptr;
     size_t order_cap = 0;
+    std::vector<unsigned> order_sig;   // group counts the order on the device was built for
     int64_t* h_state = nullptr;     // pinned: slots x 16
     int32_t* h_triple = nullptr;    // pinned: slots x 4
     unsigned* h_abort = nullptr;    // pinned: slots
@@ -1010,12 +1011,18 @@ int psa_many_clear_slot(psa_many* e, int slot) {
 
 // ONE fill launch over all bound slots, ONE launch of their walks, results copied to pinned host memory:
 // everything asynchronous on the engine's stream.
-int psa_many_launch(psa_many* e) {
+int psa_many_launch(psa_many* e) { return psa_many_launch_after(e, nullptr); }
+
+int psa_many_launch_after(psa_many* e, psa_many* after) {
     if (!e) return fail(PSA_E_ARG, "psa_many_launch: null engine");
     if (e->launched) return fail(PSA_E_STATE, "psa_many_launch: results of the last launch have not been waited for");
+    if (after && after->device != e->device) return fail(PSA_E_ARG, "psa_many_launch_after: engines on different devices");
     DeviceGuard g(e->device);
     if (g.rc) return g.rc;
     hipStream_t st = e->stream;
+    // this engine's fill begins when the other engine's fill has ended: its walks and copies then run beside
+    // this fill, and every fill launch has the chip to itself (but for those walks)
+    if (after && after != e && after->launched) HIP_TRY(hipStreamWaitEvent(st, after->ev[1], 0));
     const bool with_codes = (e->flags & PSA_F_TRACEBACK) != 0;
     psa::FillArgs2 jobs[psa::kMaxJobs];
     int slot_of[psa::kMaxJobs];
@@ -1040,19 +1047,23 @@ int psa_many_launch(psa_many* e) {
     if (nj > 0) {
         const uint32_t* order_dev = nullptr;
         if (nj > 1) {   // round-robin over the jobs that still have groups left
-            std::vector<uint32_t> order;
-            order.reserve(total);
-            for (unsigned r = 0; r < rounds; ++r)
-                for (int j = 0; j < nj; ++j)
-                    if (r < groups[j]) order.push_back(((uint32_t)j << psa::kOrderJobShift) | r);
-            if (e->order_cap < order.size()) {
-                hipFree(e->order);
-                e->order = nullptr; e->order_cap = 0;
-                HIP_TRY(hipMalloc(&e->order, sizeof(uint32_t) * order.size()));
-                e->order_cap = order.size();
+            const std::vector<unsigned> sig(groups, groups + nj);
+            if (sig != e->order_sig) {   // (the same sizes as last time: the order on the device still holds)
+                std::vector<uint32_t> order;
+                order.reserve(total);
+                for (unsigned r = 0; r < rounds; ++r)
+                    for (int j = 0; j < nj; ++j)
+                        if (r < groups[j]) order.push_back(((uint32_t)j << psa::kOrderJobShift) | r);
+                if (e->order_cap < order.size()) {
+                    hipFree(e->order);
+                    e->order = nullptr; e->order_cap = 0;
+                    HIP_TRY(hipMalloc(&e->order, sizeof(uint32_t) * order.size()));
+                    e->order_cap = order.size();
+                }
+                HIP_TRY(hipMemcpyAsync(e->order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));   // (the vector goes out of scope; the copy is a few KB)
+                e->order_sig = sig;
             }
-            HIP_TRY(hipMemcpyAsync(e->order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));   // (the vector goes out of scope; the copy is a few KB)
             order_dev = e->order;
         }
         HIP_TRY(hipMemsetAsync(e->ticket, 0, 256, st));
@@ -1209,7 +1220,7 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
             if (k < npairs) { rc = psa_many_set_pair(eng[turn], sl, a[k], n[k], b[k], m[k]); held[turn].push_back(k); }
             else rc = psa_many_clear_slot(eng[turn], sl);
         }
-        if (rc == PSA_OK) rc = psa_many_launch(eng[turn]);
+        if (rc == PSA_OK) rc = psa_many_launch_after(eng[turn], eng[turn ^ 1]);
     }
     for (int x = 0; x < 2 && rc == PSA_OK; ++x) if (!held[x].empty()) rc = collect(x);
     for (int x = 0; x < 2; ++x) free_many(eng[x]);
