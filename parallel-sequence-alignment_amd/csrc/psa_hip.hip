@@ -1029,7 +1029,6 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
     unsigned groups[psa::kMaxJobs];
     int nj = 0;
     unsigned total = 0, rounds = 0;
-    HIP_TRY(hipEventRecord(e->ev[0], st));
     for (int k = 0; k < e->slots; ++k) {
         if (e->bound[k] != 1) continue;
         psa_stripe* s = e->st[k];
@@ -1067,9 +1066,10 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
             order_dev = e->order;
         }
         HIP_TRY(hipMemsetAsync(e->ticket, 0, 256, st));
+        HIP_TRY(hipEventRecord(e->ev[0], st));   // (the events bracket the fill launch itself)
         if (int rc = launch_fill_v2(jobs, nj, order_dev, total, e->ticket, with_codes,
                                     nj > 1 ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes, st)) return rc;
-    }
+    } else HIP_TRY(hipEventRecord(e->ev[0], st));
     HIP_TRY(hipEventRecord(e->ev[1], st));
     // the walks: one wavefront per pair, all in one launch, each starting from its pair's final pick
     if (with_codes) {
