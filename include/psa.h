@@ -139,6 +139,17 @@ int psa_score_batch_dev(const uint8_t* seqs_dev, const int64_t* offsets_dev, con
                         int64_t npairs, int max_len_b, int32_t* scores_dev, unsigned* counter_dev,
                         void* stream);
 
+/* psa_score_batch_dev for callers that cannot allocate device memory and have no workspace to hand
+ * over: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No
+ * counterpart in the reference.  The kernel's only scratch -- its 256-byte work counter -- lives in a
+ * static device array inside the library (256 bytes per GPU, held until the process ends); the call
+ * performs no hipMalloc / hipFree and calls no allocating routine.  Limits: npairs <= 2^30 per call,
+ * max_len_b <= 1024 (as psa_score_batch_dev); beyond them PSA_E_ARG with a message.  Every call on a
+ * GPU shares that GPU's counter, which the call re-zeroes on `stream`: calls that overlap in time on
+ * one GPU (different streams or threads) race and must be serialised by the caller. */
+int psa_score_batch_dev_noalloc(const uint8_t* seqs_dev, const int64_t* offsets_dev, const int32_t* pairs_dev,
+                                int64_t npairs, int max_len_b, int32_t* scores_dev, void* stream);
+
 /* The five stdout lines of the reference (simple.cpp:312-313, output_alignement 43-70) for a
  * result; returned buffer is released with psa_free(), *out_len is its length in bytes. */
 char* psa_format_result(int32_t score, const uint8_t* a, const uint8_t* b, const int32_t* ai,

@@ -39,6 +39,7 @@ _SIGNATURES = {
     "psa_score_batch": (C.c_int, [C.c_void_p, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p]),
     "psa_score_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
+    "psa_score_batch_dev_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_int, C.c_void_p, C.c_void_p]),
     "psa_format_result": (C.c_void_p, [_i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64, _i64p]),
     "psa_finish_alignment": (C.c_int, [C.c_void_p, C.c_void_p, _i64, _i64, _i64p]),
     "psa_stripe_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, _i64, C.c_void_p, _i64, _i64, _i64,

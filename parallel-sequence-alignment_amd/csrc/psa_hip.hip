@@ -1305,6 +1305,51 @@ int psa_score_batch_dev(const uint8_t* seqs_dev, const int64_t* offsets_dev, con
 }
 
 
+}  // extern "C"
+
+// ---- psa_score_batch_dev without any allocation and without a workspace argument ----
+// The batch kernel's scratch -- its work counter, the only device memory it uses beyond inputs and outputs --
+// lives in this file-scope device array (256 bytes on every GPU the library runs on, until the process ends).
+// In host code the array's NAME is only a stand-in: the address kernels and memsets get is the one
+// hipGetSymbolAddress returns for the current device, looked up once per device and kept.
+static __device__ __align__(256) unsigned scratch[64];
+
+namespace {
+constexpr int kMaxScratchDevices = 64;
+constexpr int64_t kNoAllocMaxPairs = 1LL << 30;   // the counter is 32 bits wide; the kernel adds to it once per pair and wave
+unsigned* g_scratch_ptr[kMaxScratchDevices] = {nullptr};
+
+int scratch_for_current_device(unsigned** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kMaxScratchDevices) return fail(PSA_E_ARG, "device %d: only devices 0..%d have a scratch slot", dev, kMaxScratchDevices - 1);
+    unsigned* ptr = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!ptr) {   // first call on this device (it is current): ask the runtime where this GPU's copy of the array lies
+        HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(PSA_E_HIP, "hipGetSymbolAddress returned a null address for the scratch array");
+        __atomic_store_n(&g_scratch_ptr[dev], ptr, __ATOMIC_RELEASE);   // (two threads racing here store the same address)
+    }
+    *out = ptr;
+    return PSA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int psa_score_batch_dev_noalloc(const uint8_t* seqs_dev, const int64_t* offsets_dev, const int32_t* pairs_dev, int64_t npairs,
+                                int max_len_b, int32_t* scores_dev, void* stream) {
+    if (npairs <= 0) return PSA_OK;
+    if (npairs > kNoAllocMaxPairs)
+        return fail(PSA_E_ARG, "psa_score_batch_dev_noalloc: %lld pairs exceed the maximum of %lld per call", (long long)npairs,
+                    (long long)kNoAllocMaxPairs);
+    if (int rc = need_device()) return rc;
+    unsigned* ptr = nullptr;
+    if (int rc = scratch_for_current_device(&ptr)) return rc;
+    // (psa_score_batch_dev zeroes the counter it is handed -- here this GPU's scratch, which still holds the
+    // last call's count -- and launches the kernel; it allocates nothing)
+    return psa_score_batch_dev(seqs_dev, offsets_dev, pairs_dev, npairs, max_len_b, scores_dev, ptr, stream);
+}
+
 // simple.cpp:312 + output_alignement (simple.cpp:43-70); both Length lines print al_A's size.
 char* psa_format_result(int32_t score, const uint8_t* a, const uint8_t* b, const int32_t* ai, const int32_t* bj,
                         int64_t len, int64_t* out_len) {
