@@ -243,6 +243,28 @@ uint8_t* psa_read_fasta(const char* path, int64_t* len_out);
  * or PSA_E_ARG (file cannot be opened; the reference's message goes to stderr). */
 int psa_read_fasta_records(const char* path, uint8_t** seqs_out, int64_t** offsets_out, int64_t* nrec_out);
 
+/* ---- batch input resident on the device (no counterpart in the reference) ----------
+ * A psa_seqset holds many sequences in the layout psa_score_batch_dev takes -- all residues back to
+ * back in device memory plus an offsets array -- loaded from multi-record FASTA files and/or
+ * directories of FASTA files: every path is a file (each '>' record one sequence, line handling as
+ * psa_read_fasta_records) or a directory (every regular file in it, in byte order of the names).
+ * Staged through pinned host memory; the host copy is kept (names, lengths, fallback for long pairs).
+ * psa_seqset_score_block scores records [q0, q1) against records [t0, t1) -- the pair list is made on
+ * the device, targets longer than 1024 residues go through psa_score -- into
+ * scores_out[(q - q0) * (t1 - t0) + (t - t0)].  The reference's own CLI still concatenates all
+ * records of a file (read_fasta.cpp:16-19 = psa_read_fasta). */
+typedef struct psa_seqset psa_seqset;
+int psa_seqset_load(psa_seqset** out, const char* const* paths, int npaths);
+void psa_seqset_destroy(psa_seqset* s);
+int64_t psa_seqset_count(const psa_seqset* s);
+int64_t psa_seqset_length(const psa_seqset* s, int64_t i);
+const char* psa_seqset_name(const psa_seqset* s, int64_t i);
+const uint8_t* psa_seqset_residues(const psa_seqset* s, int64_t i);      /* host copy of record i */
+const uint8_t* psa_seqset_seqs_dev(const psa_seqset* s);                 /* device: all residues */
+const int64_t* psa_seqset_offsets_dev(const psa_seqset* s);              /* device: count + 1 offsets */
+int psa_seqset_score_block(const psa_seqset* s, int64_t q0, int64_t q1, int64_t t0, int64_t t1,
+                           int32_t* scores_out);
+
 /* Synthetic iid-uniform protein over ACDEFGHIKLMNPQRSTVWY: out[k] = alphabet[g() % 20] with
  * std::mt19937_64 g(seed).  Host-side. */
 void psa_synth_protein(uint64_t seed, int64_t n, uint8_t* out);

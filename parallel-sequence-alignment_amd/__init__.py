@@ -12,6 +12,7 @@ from .binding import (  # noqa: F401
     Many,
     PsaError,
     Result,
+    SeqSet,
     Stripe,
     align,
     align_many,

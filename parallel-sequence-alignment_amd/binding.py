@@ -1,6 +1,7 @@
 """ctypes binding of include/psa.h (the reference-side binding a maintainer would add)."""
 import ctypes as C
 import os
+import sys
 from collections import namedtuple
 
 import numpy as np
@@ -57,6 +58,15 @@ _SIGNATURES = {
     "psa_read_fasta_records": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i64p]),
     "psa_synth_protein": (None, [C.c_uint64, _i64, C.c_void_p]),
     "psa_release_cache": (None, []),
+    "psa_seqset_load": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_char_p), C.c_int]),
+    "psa_seqset_destroy": (None, [C.c_void_p]),
+    "psa_seqset_count": (_i64, [C.c_void_p]),
+    "psa_seqset_length": (_i64, [C.c_void_p, _i64]),
+    "psa_seqset_name": (C.c_char_p, [C.c_void_p, _i64]),
+    "psa_seqset_residues": (C.c_void_p, [C.c_void_p, _i64]),
+    "psa_seqset_seqs_dev": (C.c_void_p, [C.c_void_p]),
+    "psa_seqset_offsets_dev": (C.c_void_p, [C.c_void_p]),
+    "psa_seqset_score_block": (C.c_int, [C.c_void_p, _i64, _i64, _i64, _i64, C.c_void_p]),
     "psa_align_many": (C.c_int, [_i64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "psa_many_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, _i64, _i64, C.c_uint32]),
@@ -81,6 +91,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(lib_path):
             raise PsaError(-2, "%s is missing: run `make` (there is no CPU fallback)" % lib_path)
+        if "torch" in sys.modules:   # torch brings its own HIP runtime, which must see the GPU first
+            try:
+                if sys.modules["torch"].cuda.is_available():
+                    sys.modules["torch"].cuda.init()
+            except Exception:
+                pass
         L = C.CDLL(lib_path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
@@ -227,6 +243,44 @@ def synth_protein(seed, n):
     out = np.zeros(int(n), np.uint8)
     lib().psa_synth_protein(C.c_uint64(seed), int(n), _ptr(out))
     return out
+
+
+class SeqSet:
+    """Sequences resident on the device, loaded from FASTA files / directories (psa_seqset_*)."""
+
+    def __init__(self, paths):
+        if isinstance(paths, (str, bytes, os.PathLike)):
+            paths = [paths]
+        arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+        self._h = C.c_void_p()
+        _check(lib().psa_seqset_load(C.byref(self._h), arr, len(paths)))
+
+    def close(self):
+        if self._h:
+            lib().psa_seqset_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __len__(self):
+        return lib().psa_seqset_count(self._h)
+
+    def name(self, i):
+        return lib().psa_seqset_name(self._h, i).decode("utf-8", "replace")
+
+    def residues(self, i):
+        return C.string_at(lib().psa_seqset_residues(self._h, i), lib().psa_seqset_length(self._h, i))
+
+    def seqs_dev(self):
+        return lib().psa_seqset_seqs_dev(self._h)
+
+    def offsets_dev(self):
+        return lib().psa_seqset_offsets_dev(self._h)
+
+    def score_block(self, q0, q1, t0, t1):
+        out = np.zeros((q1 - q0, t1 - t0), np.int32)
+        _check(lib().psa_seqset_score_block(self._h, q0, q1, t0, t1, _ptr(out)))
+        return out
 
 
 def release_cache():

@@ -614,14 +614,14 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
         } else {
             o1 = p.left[yo]; o2 = p.left[R + yo]; o3 = p.left[2 * R + yo];
             if (yo >= 1) { u1 = p.left[yo - 1]; u2 = p.left[R + yo - 1]; u3 = p.left[2 * R + yo - 1]; }
-            else if (p.r0 > 0) { u1 = p.corner[0]; u2 = p.corner[1]; u3 = p.corner[2]; }
+            else if (p.r0 > 0) { if (!take_corner(p, u1, u2, u3)) u1 = u2 = u3 = 0; }   // (gave up: the abort flag is set)
             else boundary_triple(0, c0, u1, u2, u3);
         }
     } else {
         boundary_triple(i, 0, o1, o2, o3);
         boundary_triple(i - 1, 0, u1, u2, u3);
     }
-    if (i == p.r1) { p.corner_next[0] = o1; p.corner_next[1] = o2; p.corner_next[2] = o3; }
+    if (p.left && !p.left_done && s == 0 && lane == 0 && p.r1 < p.n) publish_corner(p, R);
     const int bias_own = (int)(3 * (i + c0));
     const int D_own = max3i(o1, o2, o3) + bias_own;
     const int D_up = max3i(u1, u2, u3) + bias_own - 3;

@@ -300,7 +300,10 @@ int prepare_fill(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev,
         // runs ahead of the strips it should follow and overwrites ring slots they have not read yet.
         // (A banded refill takes its input from the checkpoint row, never from the ring.)
         HIP_TRY(hipMemsetAsync(s->ring, 0, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64), st));
-        if (r0 == 0) s->corner_cur = 0;
+        if (r0 == 0) {
+            s->corner_cur = 0;
+            HIP_TRY(hipMemsetAsync(s->small, 0, 256, st));   // corner slots are recognised by their tag (a row number): none may survive a pass
+        }
         HIP_TRY(hipMemsetAsync(s->ctrl + kAbortWord, 0, kCtrlLaunchBytes, st));
     }
     // a control block of its own for every launch: the previous chunk's launch may still be running
@@ -1431,6 +1434,170 @@ int psa_read_fasta_records(const char* path, uint8_t** seqs_out, int64_t** offse
     for (size_t r = 0; r < starts.size(); ++r) off[r] = starts[r];
     off[starts.size()] = (int64_t)seq.size();
     *seqs_out = buf; *offsets_out = off; *nrec_out = (int64_t)starts.size();
+    return PSA_OK;
+}
+
+}  // extern "C"
+
+// ---- batch input resident on the device: FASTA records / directories -> seqs + offsets in HBM ----
+struct psa_seqset {
+    int device = 0;
+    int64_t count = 0, total = 0;
+    int max_len = 0;
+    uint8_t* h_seqs = nullptr;     // pinned host staging (kept: the fallback for over-long pairs reads it)
+    int64_t* h_off = nullptr;      // pinned
+    uint8_t* d_seqs = nullptr;
+    int64_t* d_off = nullptr;
+    std::vector<std::string> names;   // header line of every record (without '>'), or the file name
+};
+
+namespace {
+
+// one file: every '>' record its own sequence, line handling of read_fasta.cpp:16-19 (see psa_read_fasta_records)
+int append_fasta_file(const std::string& path, std::string& seq, std::vector<int64_t>& starts, std::vector<std::string>& names) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) {
+        fprintf(stderr, "Error opening file: %s\n", path.c_str());
+        return fail(PSA_E_ARG, "psa_seqset_load: cannot open %s", path.c_str());
+    }
+    std::string line;
+    int ch;
+    bool any = false, have_record = false;
+    auto flush = [&]() {
+        if (!line.empty() && line[0] == '>') { starts.push_back((int64_t)seq.size()); names.push_back(line.substr(1)); have_record = true; }
+        else if (!line.empty()) {
+            if (!have_record) { starts.push_back((int64_t)seq.size()); names.push_back(path); have_record = true; }   // residues before any header
+            seq += line;
+        }
+        line.clear();
+    };
+    while ((ch = fgetc(f)) != EOF) {
+        any = true;
+        if (ch == '\n') flush(); else line.push_back((char)ch);
+    }
+    if (any) flush();
+    fclose(f);
+    return PSA_OK;
+}
+
+__global__ void block_pairs_kernel(int32_t* pairs, int q0, int nq, int t0, int nt) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (int64_t)nq * nt) return;
+    pairs[2 * k] = q0 + (int32_t)(k / nt);
+    pairs[2 * k + 1] = t0 + (int32_t)(k % nt);
+}
+
+}  // namespace
+
+#include <dirent.h>
+#include <sys/stat.h>
+
+extern "C" {
+
+void psa_seqset_destroy(psa_seqset* s) {
+    if (!s) return;
+    DeviceGuard g(s->device);
+    hipFree(s->d_seqs); hipFree(s->d_off);
+    hipHostFree(s->h_seqs); hipHostFree(s->h_off);
+    delete s;
+}
+
+int psa_seqset_load(psa_seqset** out, const char* const* paths, int npaths) {
+    if (!out || npaths < 0 || (npaths && !paths)) return fail(PSA_E_ARG, "psa_seqset_load: bad argument");
+    *out = nullptr;
+    if (int rc = need_device()) return rc;
+    std::string seq;
+    std::vector<int64_t> starts;
+    std::vector<std::string> names;
+    for (int k = 0; k < npaths; ++k) {
+        if (!paths[k]) return fail(PSA_E_ARG, "psa_seqset_load: null path");
+        struct stat sb;
+        if (stat(paths[k], &sb) == 0 && S_ISDIR(sb.st_mode)) {
+            // a directory: every regular file in it, in byte order of the names
+            std::vector<std::string> files;
+            if (DIR* d = opendir(paths[k])) {
+                while (struct dirent* de = readdir(d)) {
+                    const std::string full = std::string(paths[k]) + "/" + de->d_name;
+                    struct stat fs;
+                    if (stat(full.c_str(), &fs) == 0 && S_ISREG(fs.st_mode)) files.push_back(full);
+                }
+                closedir(d);
+            } else return fail(PSA_E_ARG, "psa_seqset_load: cannot read directory %s", paths[k]);
+            std::sort(files.begin(), files.end());
+            for (auto& f : files) if (int rc = append_fasta_file(f, seq, starts, names)) return rc;
+        } else if (int rc = append_fasta_file(paths[k], seq, starts, names)) return rc;
+    }
+    psa_seqset* s = new psa_seqset();
+    if (hipGetDevice(&s->device) != hipSuccess) s->device = 0;
+    s->count = (int64_t)starts.size(); s->total = (int64_t)seq.size(); s->names = names;
+#define SET_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) { psa_seqset_destroy(s); return fail(e_ == hipErrorOutOfMemory ? PSA_E_NOMEM : PSA_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+    } while (0)
+    SET_TRY(hipHostMalloc(&s->h_seqs, seq.size() + 64));
+    SET_TRY(hipHostMalloc(&s->h_off, sizeof(int64_t) * (starts.size() + 1)));
+    memcpy(s->h_seqs, seq.data(), seq.size());
+    for (size_t r = 0; r < starts.size(); ++r) s->h_off[r] = starts[r];
+    s->h_off[starts.size()] = (int64_t)seq.size();
+    for (int64_t r = 0; r < s->count; ++r) s->max_len = (int)std::max<int64_t>(s->max_len, s->h_off[r + 1] - s->h_off[r]);
+    SET_TRY(hipMalloc(&s->d_seqs, seq.size() + 64));
+    SET_TRY(hipMalloc(&s->d_off, sizeof(int64_t) * (starts.size() + 1)));
+    SET_TRY(hipMemcpyAsync(s->d_seqs, s->h_seqs, seq.size(), hipMemcpyHostToDevice, nullptr));
+    SET_TRY(hipMemcpyAsync(s->d_off, s->h_off, sizeof(int64_t) * (starts.size() + 1), hipMemcpyHostToDevice, nullptr));
+    SET_TRY(hipStreamSynchronize(nullptr));
+#undef SET_TRY
+    *out = s;
+    return PSA_OK;
+}
+
+int64_t psa_seqset_count(const psa_seqset* s) { return s ? s->count : 0; }
+int64_t psa_seqset_length(const psa_seqset* s, int64_t i) { return (s && i >= 0 && i < s->count) ? s->h_off[i + 1] - s->h_off[i] : -1; }
+const char* psa_seqset_name(const psa_seqset* s, int64_t i) { return (s && i >= 0 && i < s->count) ? s->names[(size_t)i].c_str() : nullptr; }
+const uint8_t* psa_seqset_seqs_dev(const psa_seqset* s) { return s ? s->d_seqs : nullptr; }
+const int64_t* psa_seqset_offsets_dev(const psa_seqset* s) { return s ? s->d_off : nullptr; }
+const uint8_t* psa_seqset_residues(const psa_seqset* s, int64_t i) { return (s && i >= 0 && i < s->count) ? s->h_seqs + s->h_off[i] : nullptr; }
+
+// scores_out[(q - q0) * (t1 - t0) + (t - t0)] = result.score of run(p, record q, record t)
+int psa_seqset_score_block(const psa_seqset* s, int64_t q0, int64_t q1, int64_t t0, int64_t t1, int32_t* scores_out) {
+    if (!s || !scores_out || q0 < 0 || q1 < q0 || q1 > s->count || t0 < 0 || t1 < t0 || t1 > s->count)
+        return fail(PSA_E_ARG, "psa_seqset_score_block: bad argument");
+    const int64_t nq = q1 - q0, nt = t1 - t0, np = nq * nt;
+    if (np == 0) return PSA_OK;
+    if (np > (1LL << 30)) return fail(PSA_E_ARG, "psa_seqset_score_block: at most 2^30 pairs per call");
+    DeviceGuard g(s->device);
+    if (g.rc) return g.rc;
+    int32_t *d_pairs = nullptr, *d_scores = nullptr;
+    unsigned* d_ctr = nullptr;
+    auto cleanup = [&]() { hipFree(d_pairs); hipFree(d_scores); hipFree(d_ctr); };
+#define BLK_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) { cleanup(); return fail(PSA_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } \
+    } while (0)
+    BLK_TRY(hipMalloc(&d_pairs, sizeof(int32_t) * 2 * (size_t)np));
+    BLK_TRY(hipMalloc(&d_scores, sizeof(int32_t) * (size_t)np));
+    BLK_TRY(hipMalloc(&d_ctr, 256));
+    hipLaunchKernelGGL(block_pairs_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, nullptr, d_pairs, (int)q0, (int)nq, (int)t0, (int)nt);
+    int max_b = 0;
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t lb = s->h_off[t + 1] - s->h_off[t];
+        if (lb <= psa::kBatchMaxLen) max_b = std::max(max_b, (int)lb);
+    }
+    int rc = psa_score_batch_dev(s->d_seqs, s->d_off, d_pairs, np, max_b, d_scores, d_ctr, nullptr);
+    if (rc == PSA_OK) BLK_TRY(hipMemcpy(scores_out, d_scores, sizeof(int32_t) * (size_t)np, hipMemcpyDeviceToHost));
+#undef BLK_TRY
+    cleanup();
+    if (rc != PSA_OK) return rc;
+    // targets longer than the batch kernel's row buffer: through the single-pair path
+    for (int64_t t = t0; t < t1; ++t) {
+        if (s->h_off[t + 1] - s->h_off[t] <= psa::kBatchMaxLen) continue;
+        for (int64_t q = q0; q < q1; ++q) {
+            rc = psa_score(s->h_seqs + s->h_off[q], s->h_off[q + 1] - s->h_off[q], s->h_seqs + s->h_off[t], s->h_off[t + 1] - s->h_off[t], 1,
+                           &scores_out[(q - q0) * nt + (t - t0)], nullptr);
+            if (rc != PSA_OK) return rc;
+        }
+    }
     return PSA_OK;
 }
 

@@ -23,8 +23,9 @@ struct FillArgs {
     int Q;                   // blocks of 64 steps per strip = ceil((W+63)/64)
     int Wpad;                // ring pitch (granules per parity)
     const int32_t* left;     // [3][R] plain T1,T2,T3 at column c0 for rows r0+1..r1; null = column 0
-    const int32_t* corner;   // [3] plain triple at (r0, c0) when left != null and r0 > 0
-    int32_t* corner_next;    // [3] receives the triple at (r1, c0)
+    const int32_t* corner;   // [4] plain triple at (r0, c0) and the tag r0, when left != null and r0 > 0: published by
+    int32_t* corner_next;    // the chunk above (its first strip stores {left triple of row r1, tag r1} here), which may
+                             // still be running -- chunks of one stripe are launched on alternating streams
     int32_t* right;          // [3][R] plain triple at column c0+W, or null
     const unsigned* left_done;  // stripes of one pair filled by ONE launch: left_done[strip] != 0 once the stripe on the
     unsigned* right_done;       // left has stored that strip's rows of `left`; this stripe raises right_done[strip]
@@ -47,6 +48,34 @@ __device__ __forceinline__ u64* ckpt_row_out(const FillArgs& p, int64_t sg) {
 }
 __device__ __forceinline__ const u64* ckpt_row_in(const FillArgs& p, int64_t sg) {
     return (p.band_strips > 0 && sg > 0 && sg % p.band_strips == 0) ? p.ckpt + (size_t)(sg / p.band_strips) * p.Wpad : nullptr;
+}
+
+// The triple at (r1, c0) for the chunk below: the last row of this chunk's left boundary.  Published by the FIRST
+// strip of a chunk (the chunk below may be launched while this one runs and needs it at once), tag last.
+__device__ __forceinline__ void publish_corner(const FillArgs& p, int64_t R) {
+    __hip_atomic_store(p.corner_next + 0, p.left[R - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.corner_next + 1, p.left[2 * R - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p.corner_next + 2, p.left[3 * R - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(p.corner_next + 3, (int32_t)p.r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ... and its reader: waits (bounded) for the tag of this chunk's first row; false = gave up
+__device__ __forceinline__ bool take_corner(const FillArgs& p, int& u1, int& u2, int& u3) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(p.corner + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)p.r0) break;
+        __builtin_amdgcn_s_sleep(8);
+        if ((spins & 1023u) == 1023u) {
+            const unsigned ab = __hip_atomic_load(p.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ab || spins > (1u << 26)) {
+                __hip_atomic_store(p.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+    u1 = __hip_atomic_load(p.corner + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u2 = __hip_atomic_load(p.corner + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u3 = __hip_atomic_load(p.corner + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
 }
 
 __device__ __forceinline__ u64 load_granule(const u64* p) {
@@ -80,13 +109,13 @@ __global__ __launch_bounds__(64) void fill_strips_v1(FillArgs p) {
         const int64_t yo = row_ok ? y : (R - 1);
         o1 = p.left[yo]; o2 = p.left[R + yo]; o3 = p.left[2 * R + yo];
         if (yo >= 1) { u1 = p.left[yo - 1]; u2 = p.left[R + yo - 1]; u3 = p.left[2 * R + yo - 1]; }
-        else if (p.r0 > 0) { u1 = p.corner[0]; u2 = p.corner[1]; u3 = p.corner[2]; }
+        else if (p.r0 > 0) { if (!take_corner(p, u1, u2, u3)) u1 = u2 = u3 = 0; }   // (gave up: the abort flag is set)
         else boundary_triple(0, c0, u1, u2, u3);
+        if (s == 0 && lane == 0 && p.r1 < p.n) publish_corner(p, R);
     } else {
         boundary_triple(i, 0, o1, o2, o3);
         boundary_triple(i - 1, 0, u1, u2, u3);
     }
-    if (i == p.r1) { p.corner_next[0] = o1; p.corner_next[1] = o2; p.corner_next[2] = o3; }
     const int bias_own = (int)(3 * (i + c0));
     const int bias_up = bias_own - 3;
     const int D_own = max3i(o1, o2, o3) + bias_own;

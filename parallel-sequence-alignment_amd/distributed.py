@@ -12,6 +12,8 @@ The compute engine is pluggable only so that the orchestration can be exercised 
 gloo in the test-suite (tests inject an oracle-backed engine); the default and only product
 engine is the HIP stripe object of the C ABI.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -26,6 +28,17 @@ class HipStripeEngine:
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.stripe = Stripe(a, b, c0, c1, traceback=traceback)
         self.n, self.m = self.stripe.n, self.stripe.m
+        # consecutive row chunks go to alternating streams: chunk c+1 is launched while chunk c runs and its
+        # first strip picks up the rows chunk c's last strip publishes (granules in HBM), so the stripe's
+        # dependency chain stays alive across chunk boundaries instead of draining at each of them
+        self.streams = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
+
+    def chunk_stream(self, c):
+        return torch.cuda.stream(self.streams[c % 2])
+
+    def sync_chunks(self):
+        for s in self.streams:
+            s.synchronize()
 
     def new_edge(self, rows):
         return torch.empty(3 * rows, dtype=torch.int32, device=self.dev)
@@ -75,17 +88,29 @@ def _recv(t, src):
         dist.recv(t, src)
 
 
-def align_striped(a, b, chunk_rows=4096, traceback=True, engine_cls=HipStripeEngine, keep_engine=None):
+def auto_chunk_rows(width):
+    """Rows per hand-off for a stripe `width` columns wide.  A chain that wide keeps about width / 450 workgroups
+    (of 256 rows) busy at a time, and two chunks are in flight: chunks that small would leave the GPU idle on a
+    wide stripe (4096 rows = 16 workgroups), chunks that large lengthen the pipeline's fill across the ranks.
+    Two chunks in flight stay below the 256 workgroups one GPU holds at a time (every strip of chunk c+1
+    waits for strips of chunk c, which must be able to get a CU)."""
+    groups = max(16, min(96, (width // 450 + 1) // 2 + 1))
+    return 256 * groups
+
+
+def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEngine, keep_engine=None):
     """Align A against B with B cut into world_size column stripes, one per rank.
 
     Every rank calls this with the same a, b.  Returns Result(score, ai, bj) on every rank
-    (ai, bj are empty arrays when traceback is False).  chunk_rows (multiple of 64) is the
-    hand-off granularity between neighbouring ranks.
+    (ai, bj are empty arrays when traceback is False).  chunk_rows (multiple of 64; None or 0: chosen
+    from the stripe width, auto_chunk_rows) is the hand-off granularity between neighbouring ranks.
     """
     world, rank = dist.get_world_size(), dist.get_rank()
     a = np.ascontiguousarray(np.frombuffer(a, np.uint8) if isinstance(a, (bytes, bytearray)) else a, np.uint8)
     b = np.ascontiguousarray(np.frombuffer(b, np.uint8) if isinstance(b, (bytes, bytearray)) else b, np.uint8)
     n, m = int(a.size), int(b.size)
+    if not chunk_rows:
+        chunk_rows = auto_chunk_rows(max(1, m // world))
     assert chunk_rows >= 64 and chunk_rows % 64 == 0
     empty = np.zeros(0, np.int32)
     if n == 0 or m == 0:
@@ -104,18 +129,24 @@ def align_striped(a, b, chunk_rows=4096, traceback=True, engine_cls=HipStripeEng
     eng = None
     if width > 0:
         eng = keep_engine if keep_engine is not None else engine_cls(a, b, c0, c1, traceback)
-        left = eng.new_edge(min(chunk_rows, n)) if prev_owner is not None else None
-        right = eng.new_edge(min(chunk_rows, n)) if next_owner is not None else None
-        for r0 in range(0, n, chunk_rows):
+        # two chunks are in flight at a time (alternating streams): two boundary buffers each way
+        left = [eng.new_edge(min(chunk_rows, n)) for _ in range(2)] if prev_owner is not None else None
+        right = [eng.new_edge(min(chunk_rows, n)) for _ in range(2)] if next_owner is not None else None
+        chunk_stream = getattr(eng, "chunk_stream", None)
+        for c, r0 in enumerate(range(0, n, chunk_rows)):
             r1 = min(n, r0 + chunk_rows)
             rows = r1 - r0
-            lv = left[:3 * rows] if left is not None else None
-            rv = right[:3 * rows] if right is not None else None
-            if lv is not None:
-                _recv(lv, prev_owner)
-            eng.fill_rows(r0, r1, lv, rv)
-            if rv is not None:
-                _send(rv, next_owner)
+            lv = left[c % 2][:3 * rows] if left is not None else None
+            rv = right[c % 2][:3 * rows] if right is not None else None
+            ctx = chunk_stream(c) if chunk_stream is not None else contextlib.nullcontext()
+            with ctx:   # recv, fill and send of one chunk are ordered on its stream; the next chunk's run beside them
+                if lv is not None:
+                    _recv(lv, prev_owner)
+                eng.fill_rows(r0, r1, lv, rv)
+                if rv is not None:
+                    _send(rv, next_owner)
+        if hasattr(eng, "sync_chunks"):
+            eng.sync_chunks()
 
     # ---- final pick on the last stripe, then the traceback chain right -> left ----
     if dist.get_backend() == "nccl":

@@ -15,3 +15,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """torch ships its own HIP runtime; libpsa_hip.so links the system one.  Both live in one process as long as
+    torch initialises the GPU first (the other order leaves torch with "No HIP GPUs are available"), so the GPU
+    session does that before any test touches the library."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield

@@ -13,7 +13,7 @@ Outputs (all committed, all data):
   ref_random.json        random protein pairs 512/1024/2048 (std::mt19937_64 stream, SURVEY 8d)
   sequences/synth_*.fasta  the inputs of ref_random.json
 Restatement-only goldens (inputs the reference cannot run, e.g. titin) are made by
-make_oracle_golden.py and are marked as such.
+make_oracle_golden.py (oracle_only.json) and are marked as such.
 
 Usage: python tests/golden/make_golden.py            (takes a few minutes)
 """

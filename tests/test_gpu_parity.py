@@ -106,6 +106,27 @@ def test_large_score_only_property():
     assert psa_amd.score(a, b, 4) == want
 
 
+def test_huge_pair_score_only_and_linear_space():
+    """BASELINE config 4's second size, 2^20 x 2^20 (1.1e12 cells): the score-only fill with p = 1 and p = 3, the
+    committed restatement-only golden score (tests/golden/oracle_only.json, made by make_oracle_golden.py) and the
+    score of the linear-space alignment all agree; the alignment's columns obey the size-independent properties."""
+    import json
+    k = 20
+    gold = [e for e in json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_only.json")))["synthetic"] if e["log2"] == k]
+    a = psa_amd.synth_protein(0xA0000000 + k, 1 << k)
+    b = psa_amd.synth_protein(0xB0000000 + k, 1 << k)
+    s1 = psa_amd.score(a, b, 1)
+    assert psa_amd.score(a, b, 3) == s1
+    if gold:
+        assert s1 == gold[0]["score"]
+    psa_amd.release_cache()
+    res = psa_amd.align(a, b, 1, band_rows=0)
+    assert res.score == s1
+    for x in (res.ai, res.bj):
+        assert np.all(np.diff(x[x >= 0]) >= 0) and x[x >= 0][-1] == (1 << k) - 1
+    assert not np.any((res.ai < 0) & (res.bj < 0))
+
+
 def test_full_size_pair_vs_oracle():
     # BASELINE config 4 at the size the metric is quoted on (2^16 x 2^16, 4.3 G cells): complete alignment,
     # every column equal to the oracle's (threads of the oracle: its striped variant, a few seconds)
@@ -135,6 +156,30 @@ def test_cli_byte_exact(golden_dir):
     assert b"Error opening file: sequences/nope.fasta" in r.stderr
     r = subprocess.run([exe, "only_one_arg"], cwd=golden_dir, capture_output=True, timeout=120)
     assert r.returncode == 1 and b"Usage:" in r.stderr and r.stdout == b""
+
+
+def test_cli_reference_format_cases(tmp_path):
+    """The reference's behaviour on FASTA-format and degenerate inputs (CRLF, multi-record, lower case, no header,
+    empty / header-only / missing files, p > m, p = 32, usage error), as the real reference produced it
+    (ref_format_cases.json), through the GPU ./simple: stdout, exit status and stderr."""
+    import base64
+    exe = os.path.join(ROOT, "simple")
+    seqdir = tmp_path / "sequences"
+    seqdir.mkdir()
+    cases = O.load_golden("ref_format_cases.json")
+    for c in cases:
+        for key, name in (("a_file_b64", c.get("a")), ("b_file_b64", c.get("b"))):
+            if name and c.get(key) is not None:
+                (seqdir / name).write_bytes(base64.b64decode(c[key]))
+    for c in cases:
+        argv = c["argv"] if "argv" in c else [c["a"], c["b"], str(c["p"])]
+        r = subprocess.run([exe] + argv, cwd=tmp_path, capture_output=True, timeout=120)
+        assert r.returncode == c["rc"], (argv, r.stderr)
+        if "argv" in c:
+            assert b"Usage:" in r.stderr and r.stdout == b""
+            continue
+        assert r.stdout == O.b64d(c["stdout_b64"]), argv
+        assert r.stderr == O.b64d(c["stderr_b64"]), argv
 
 
 def test_cli_timing_sweep(golden_dir, tmp_path):
@@ -318,3 +363,86 @@ def test_stripes_in_one_launch_at_size():
         res = psa_amd.align(a, b, p)
         assert res.score == ref.score and np.array_equal(res.ai, ref.ai) and np.array_equal(res.bj, ref.bj), p
         assert psa_amd.score(a, b, p) == ref.score
+
+
+def test_seqset_loader_records_and_directory(tmp_path):
+    """Batch input: multi-record FASTA files and a directory of FASTA files -> sequences resident on
+    the device in the layout the batch kernel takes -> all-pairs scores equal to the oracle's, pair by pair
+    (including a target longer than the batch kernel's row buffer and an empty record)."""
+    rng = np.random.default_rng(41)
+    recs = [rng.integers(65, 65 + [3, 4, 20][k % 3], ln).astype(np.uint8).tobytes()
+            for k, ln in enumerate([120, 1, 64, 300, 1500, 77, 512, 0, 255])]
+    def fasta(items, crlf=False):
+        out = b""
+        for name, r in items:
+            out += b">" + name + b"\n"
+            for x in range(0, len(r), 60):
+                out += r[x:x + 60] + b"\n"
+        return out
+    (tmp_path / "multi.fasta").write_bytes(fasta([(b"r%d" % k, recs[k]) for k in range(4)]))
+    d = tmp_path / "dir"
+    d.mkdir()
+    (d / "b.fa").write_bytes(fasta([(b"r6", recs[6]), (b"r7 empty", recs[7]), (b"r8", recs[8])]))
+    (d / "a.fa").write_bytes(fasta([(b"r4 long", recs[4]), (b"r5", recs[5])]))
+    s = psa_amd.SeqSet([str(tmp_path / "multi.fasta"), str(d)])
+    assert len(s) == 9 and [s.residues(k) for k in range(9)] == recs       # directory in name order: a.fa, b.fa
+    assert s.name(0) == "r0" and s.name(4) == "r4 long" and s.name(7) == "r7 empty"
+    got = s.score_block(0, 9, 0, 9)
+    for q in range(9):
+        for t in range(9):
+            assert got[q, t] == O.score(recs[q], recs[t]), (q, t)
+    sub = s.score_block(2, 5, 5, 9)
+    assert np.array_equal(sub, got[2:5, 5:9])
+    # the device buffers are what psa_score_batch_dev takes
+    import torch
+    pairs = torch.tensor([[0, 3], [8, 6]], dtype=torch.int32, device="cuda")
+    sc = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ctr = torch.zeros(64, dtype=torch.int32, device="cuda")
+    rc = psa_amd.lib().psa_score_batch_dev(s.seqs_dev(), s.offsets_dev(), pairs.data_ptr(), 2, 512, sc.data_ptr(), ctr.data_ptr(), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert sc.tolist() == [int(got[0, 3]), int(got[8, 6])]
+    s.close()
+
+
+def test_chunks_in_flight_on_alternating_streams():
+    """Row chunks of one stripe launched on alternating streams (chunk c+1 starts while chunk c runs: its first
+    strip takes the granules and the corner triple the chunk above publishes), for a head stripe and for a stripe
+    with a left boundary -- what distributed.py does on every rank."""
+    import torch
+    rng = np.random.default_rng(51)
+    n, m, cut = 5000, 4100, 1700
+    a = rng.integers(65, 69, n).astype(np.uint8)
+    b = np.where(rng.random(m) < 0.7, np.resize(a, m), rng.integers(65, 69, m)).astype(np.uint8)
+    sc, ai, bj = O.align(a, b)
+    s0 = psa_amd.Stripe(a, b, 0, cut, traceback=True)
+    s1 = psa_amd.Stripe(a, b, cut, m, traceback=True)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    for chunk in (512, 1024, 64 * 7):
+        edges, evs = [], []
+        for c, r0 in enumerate(range(0, n, chunk)):
+            r1 = min(n, r0 + chunk)
+            e = torch.zeros(3 * (r1 - r0), dtype=torch.int32, device="cuda")
+            edges.append(e)
+            with torch.cuda.stream(streams[c % 2]):
+                s0.fill_rows(r0, r1, None, e.data_ptr(), streams[c % 2].cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(streams[c % 2])
+                evs.append(ev)
+        for c, r0 in enumerate(range(0, n, chunk)):
+            r1 = min(n, r0 + chunk)
+            sm = streams[2 + c % 2]
+            sm.wait_event(evs[c])
+            s1.fill_rows(r0, r1, edges[c].data_ptr(), None, sm.cuda_stream)
+        torch.cuda.synchronize()
+        t = s1.final()
+        k, v = psa_amd.pick(*t)
+        assert v == sc, chunk
+        cap = 2 * (n + m) + 2
+        xa, xb = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        i, j, k, ln = s1.traceback(n, m, k, xa, xb, 0)
+        if i > 0 and j > 0:
+            i, j, k, ln = s0.traceback(i, j, k, xa, xb, ln)
+        fa, fb = psa_amd.finish_alignment(xa[:ln], xb[:ln], n, m)
+        assert np.array_equal(fa, ai) and np.array_equal(fb, bj), chunk
+    s0.close(); s1.close()

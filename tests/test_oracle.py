@@ -108,3 +108,62 @@ def test_titin_restatement_md5(golden_dir):
     out = O.stdout_for(rd("titin_homo(50).fasta"), rd("titin_mus.fasta"), 8)
     assert hashlib.md5(out).hexdigest() == "65af487c90fa2638ce05f3a6badbaaea"
     assert out.startswith(b"Score: 62103\nLength Sequence A : 35289\n")
+
+
+def test_neighbour_bounds_behind_the_one_byte_codes():
+    """The HIP traceback decodes a cell from the low four bits of D = max(T1,T2,T3) of the cell and of its three
+    neighbours (psa_device.hip.h, "winner codes").  That needs, for every interior cell, D - T_k in 0..15 for the
+    three values the reference compared there; the recurrence gives 0..8 (horizontal and vertical neighbours of
+    D differ by -3..+5, diagonal ones by 0..2 -- the bounds of the Gotoh recurrence under the reference's own
+    boundary values).  Checked here on the oracle's tables, row by row through its block function, over small
+    alphabets (ties), mutated copies with long gaps and every boundary."""
+    rng = np.random.default_rng(2024)
+    worst_e, worst_h, worst_v, worst_d = 0, [0, 0], [0, 0], [9, 0]
+    for it in range(120):
+        n, m = int(rng.integers(1, 90)), int(rng.integers(1, 90))
+        alpha = int(rng.integers(1, 6)) if it % 5 else 20
+        a = rng.integers(65, 65 + alpha, n).astype(np.uint8)
+        if it % 3 == 0:
+            b = rng.integers(65, 65 + alpha, m).astype(np.uint8)
+        else:   # a copy with substitutions and long gaps
+            src = np.concatenate([a, a, a])
+            cut = int(rng.integers(0, n))
+            b = np.concatenate([src[:cut], src[cut + int(rng.integers(0, 40)):]])[:m]
+            if b.size == 0:
+                b = a[:1]
+            b = np.where(rng.random(b.size) < 0.1, rng.integers(65, 65 + alpha, b.size), b).astype(np.uint8)
+            m = int(b.size)
+        rows = [np.array([O.boundary(0, j) for j in range(m + 1)], np.int32).T]
+        left = np.array([O.boundary(i, 0) for i in range(n + 1)], np.int32).T
+        for i in range(n):   # one row at a time: rows[i + 1] = T1,T2,T3 of row i + 1
+            bottom, _ = O.block(a, b, i, i + 1, 0, m, rows[-1], left[:, i:i + 2])
+            rows.append(bottom)
+        T = np.stack(rows, axis=1).astype(np.int64)          # [3][n + 1][m + 1]
+        D = T.max(axis=0)
+        inner = D[1:, 1:]
+        worst_e = max(worst_e, int((inner[None] - T[:, 1:, 1:]).max()))
+        dh, dv, dd = inner - D[1:, :-1], inner - D[:-1, 1:], inner - D[:-1, :-1]
+        worst_h = [min(worst_h[0], int(dh.min())), max(worst_h[1], int(dh.max()))]
+        worst_v = [min(worst_v[0], int(dv.min())), max(worst_v[1], int(dv.max()))]
+        worst_d = [min(worst_d[0], int(dd.min())), max(worst_d[1], int(dd.max()))]
+    assert worst_e <= 8, worst_e
+    assert worst_h[0] >= -3 and worst_h[1] <= 5, worst_h
+    assert worst_v[0] >= -3 and worst_v[1] <= 5, worst_v
+    assert worst_d[0] >= 0 and worst_d[1] <= 2, worst_d
+
+
+def test_restatement_only_goldens_are_what_the_generator_writes(golden_dir):
+    """tests/golden/oracle_only.json (made by make_oracle_golden.py, restatement-only): well-formed, marked, and
+    its titin entry is the md5 the GPU test uses; the 2^16 score is recomputed here (seconds)."""
+    import json
+    g = json.load(open(os.path.join(golden_dir, "oracle_only.json")))
+    assert "restatement" in g["produced_by"]
+    t = [e for e in g["titin"] if e["b"] == "titin_mus.fasta" and e["a"].startswith("titin_homo")][0]
+    assert (t["score"], t["alignment_len"], t["stdout_md5"]) == (62103, 35289, "65af487c90fa2638ce05f3a6badbaaea")
+    from make_golden_shim import synth_protein
+    e16 = [e for e in g["synthetic"] if e["log2"] == 14 or e["log2"] == 16]
+    assert e16, "no synthetic entries"
+    k = 12   # a size this test can afford every run; the committed 2^16 .. 2^20 scores come from the generator
+    a = synth_protein(0xA0000000 + k, 1 << k).encode()
+    b = synth_protein(0xB0000000 + k, 1 << k).encode()
+    assert O.score(a, b, 4) == O.score(a, b)
