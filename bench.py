@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=12)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
-    ap.add_argument("--chunk-rows", type=int, default=4096, help="rows per inter-GPU hand-off (N > 1, stripes)")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="rows per inter-GPU hand-off (N > 1, stripes); 0 = from the stripe width")
     ap.add_argument("--slots", type=int, default=8, help="pairs per launch (1..8); two engines take turns")
     ap.add_argument("--overlap-fills", action="store_true",
                     help="let the two engines' fill launches overlap (default: each fill launch alone on the chip)")
@@ -309,8 +309,13 @@ def single_gpu(args):
         # BASELINE config 5 shape: a block of 512-residue proteins, all queries x all targets, score only
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_batch
-        bb = bench_batch.measure(nq=2048, nt=256, L=512, reps=3, check=4)
+        bench_batch.measure(nq=512, nt=256, L=512, reps=1, check=0)   # warm-up
+        big = os.environ.get("PSA_BENCH_BATCH", "config5") == "config5"
+        bb = bench_batch.measure(nq=100000 if big else 2048, nt=4096 if big else 256, L=512, reps=1 if big else 3, check=4, prewarm=not big)
         bb["valu_frac"] = bb["gcups"] * OPS_PER_CELL_SCORE / 1e3 / VALU_PEAK_TOPS
+        bb["note"] = ("BASELINE config 5 on one GPU: 100 000 synthetic 512-residue queries x a block of 4 096 targets, every "
+                      "pair, score only, sequences and pair list resident in HBM (the full all-vs-all is 5e9 pairs: a "
+                      "stated block of it, SURVEY 8d)") if big else "reduced block (PSA_BENCH_BATCH != config5)"
         extra["batch_512aa_score_only"] = bb
     out["extra"] = extra
     if not args.no_cpu_baseline and world == 1:
@@ -366,7 +371,7 @@ def stripes_figures(args, dist, backend, local):
     import psa_amd
     D = importlib.import_module("parallel-sequence-alignment_amd.distributed")
     world, rank = dist.get_world_size(), dist.get_rank()
-    info = {"backend": backend, "chunk_rows": args.chunk_rows}
+    info = {"backend": backend, "chunk_rows": args.chunk_rows or "auto (distributed.auto_chunk_rows)"}
     try:
         ranks = [torch.zeros(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu") for _ in range(world)]
         dist.all_gather(ranks, torch.tensor([rank], dtype=torch.int64, device=ranks[0].device))

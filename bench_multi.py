@@ -61,10 +61,10 @@ def multi_gpu(args):
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "synthetic iid 20-letter protein pair 2^%d x 2^%d, %d column stripes of B "
                                    "(one per GPU), boundary columns streamed rank g -> g+1 by RCCL send/recv in chunks "
-                                   "of %d rows; fill with packed winner codes + traceback chain + prefix fix-up"
-                                   % (k, k, world, args.chunk_rows),
+                                   "of %d rows; fill with one-byte winner codes + traceback chain + prefix fix-up"
+                                   % (k, k, world, args.chunk_rows or D.auto_chunk_rows(m // world)),
                        "n": n, "m": m, "score": int(res.score), "alignment_len": int(len(res.ai)), "stripes": world,
-                       "chunk_rows": args.chunk_rows},
+                       "chunk_rows": args.chunk_rows or D.auto_chunk_rows(m // world)},
             "roofline": {"bound": "valu", "achieved": gcups * OPS_PER_CELL_CODES / 1e3,
                          "peak": VALU_PEAK_TOPS * world, "unit": "Tint32op/s",
                          "frac": gcups * OPS_PER_CELL_CODES / 1e3 / (VALU_PEAK_TOPS * world),
