@@ -466,8 +466,7 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     if (getenv("PSA_TRACE_STATS")) {
         fprintf(stderr, "traceback: len %lld passes %lld tiles %lld single-cell steps %lld misses %lld\n", (long long)state[4],
                 (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)(state[7] >> 32), (long long)(state[7] & 0xffffffff));
-        fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld; sections %lld %lld %lld %lld\n", (long long)state[8], (long long)state[9],
-                (long long)(state[10] >> 32), (long long)(state[10] & 0xffffffff), (long long)(state[11] >> 32), (long long)(state[11] & 0xffffffff));
+        fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld (the counts above need a -DPSA_TB_STATS build)\n", (long long)state[8], (long long)state[9]);
     }
     if (state[5] == 2) return fail(PSA_E_KERNEL, "traceback: winner codes failed the decode check (values that cannot belong to one cell)");
     if (state[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow");

@@ -326,31 +326,42 @@ __global__ __launch_bounds__(64) void traceback_v1(TraceArgs p) {
 }
 
 // ---- traceback, wave-cooperative (production): one wavefront walks ----
-//   * code tiles (4 KB: 64 rows x 64 wavefront steps, the unit the fill kernel writes) are cached in
-//     LDS, re-laid out as [row][64 steps] by the fetch itself (each lane of the LDS-DMA names its own
-//     source address), together with the residues they span (64 bytes of A, 128 bytes of B); tiles
-//     are fetched ahead of the walk along its current diagonal, and using a tile waits only for that
-//     tile's fetch: "all but the N most recent vector-memory operations are complete", N = the
-//     operations issued after it.  To make N known exactly the output columns go out through buffer
-//     stores that are issued unconditionally, two per pass (lanes with nothing to write aim past the end);
-//   * the tile directory (which tile sits in which LDS slot, and the issue number of its fetch)
-//     lives in lanes 0..15 of two VGPRs: a lookup is one compare + ballot, no LDS round trip;
-//   * one pass = one step of any kind followed by the diagonal run behind it: lane l decodes the cell
-//     of the diagonal through the predecessor cell that lies in row l of the strip -- its own code
-//     byte, those of its left, upper and upper-left neighbours and the two residues, taken from the
-//     tile itself, the tile to its left or, for row 0, the tile of the strip above --, the compares'
-//     lane masks give the length of the run of "table 1 wins", the lanes emit the run's columns in
-//     parallel, and the non-diagonal step that ends the run is taken in the same pass;
-//   * cells whose neighbours lie on the matrix boundary, on the stripe's left boundary column or in
-//     the row above a band are decoded one at a time (rare);
-//   * the walk state (i, j, table, output length, tile ids) is 32-bit and wave-uniform (SGPRs);
-//     the host checks that the stripe's coordinates and tile count fit (else traceback_v1 runs).
-constexpr int kTbSlots = 16;
-constexpr int kTbA = kTileBytes;          // slot layout: tile [64 rows][64 steps], A[64 rows] at kTbA,
-constexpr int kTbB = kTileBytes + 64;     // B[128 columns from 64 q - 64] at kTbB, 192 bytes the fetch spills into
-constexpr int kTbSlotBytes = kTileBytes + 384;
-constexpr int kTbAhead = 6;
-constexpr int kTbFetchOps = 6;            // vector-memory operations per tile fetch
+// A lone wavefront issues one instruction every four to five cycles whatever the instruction, so the
+// walk is written for a low instruction count per tile entered and per pass:
+//   * cells are addressed by (row, u), u = column-in-stripe + row: a global version of the "wavefront step"
+//     the fill kernel stores by.  In these coordinates the neighbours of a cell are (row, u-1) left,
+//     (row-1, u-1) up and (row-1, u-2) diagonal, across strip and block boundaries alike, and the code tile
+//     of strip s, block q holds rows 64 s .. 64 s + 63 x steps u in [64 g, 64 g + 64), g = s + q;
+//   * LDS holds a direct-mapped window of 16 tiles: tile (s, g) lives in plane g & 3, rows (64 s) & 255 of a
+//     [4 planes][256 rows][64 steps] image, so a cell's LDS address is a bit merge of its row and step (no
+//     directory look-up per cell); the fetch is four LDS-DMA instructions that re-lay the tile [row][step]
+//     (each lane names its own 16 source bytes).  Residues sit in two 1 KB rings (A by row, B by column),
+//     fetched 256 at a time two blocks ahead;
+//   * the directory (tile id per slot and the number of the vector-memory operation that completed its
+//     fetch) lives in lanes 0..15 of two VGPRs: a look-up is a v_readlane + compare.  Using a tile waits
+//     only for that tile's fetch: "all but the N most recent vector-memory operations are complete";
+//   * entering a tile looks up the tiles to its left and above; those present widen the rectangle of
+//     (row, u) in which every lane of a pass may read, those absent narrow it (they are fetched when the
+//     walk needs them, normally ahead of time: fetches run kTbAhead tiles ahead along the walk's diagonal);
+//   * one pass = one step of any kind followed by the diagonal run behind it: lane d decodes the cell d
+//     rows up the diagonal through the predecessor cell -- its own code byte and those of its left, upper
+//     and upper-left neighbours plus the two residues --, the compares' lane masks give the length of the
+//     run of "table 1 wins", the lanes emit the run's columns in parallel (buffer stores whose range check
+//     drops the lanes past the run), and the non-diagonal step that ends the run is taken in the same pass;
+//   * cells whose neighbours lie on the matrix boundary, on the stripe's left boundary column, in the row
+//     above a band or in a tile that is not in LDS are decoded one at a time (rare);
+//   * the walk state (row, u, table, output length) is 32-bit and wave-uniform (SGPRs); the host checks
+//     that the stripe's coordinates and tile count fit (else traceback_v1 runs).
+constexpr int kTbPlaneBytes = 16384;              // [256 rows][64 steps]
+constexpr int kTbCodeBytes = 4 * kTbPlaneBytes;   // planes g & 3
+constexpr int kTbRingA = 0;                       // A[row & 1023]
+constexpr int kTbRingB = 1024;                    // B[column & 1023]
+constexpr int kTbCodes = 2048;                    // (the rings come first: every address fits the 16-bit offset field)
+constexpr int kTbLdsBytes = kTbCodes + kTbCodeBytes;
+constexpr int kTbCorner = 4;                      // a diagonal that leaves a tile within this many rows of its corner: fetch the tiles beside it too
+constexpr int kTbAheadRows = 128;                 // the fetches run this many rows (about six tiles) ahead; the window is four strips tall
+constexpr int kTbFetchOps = 4;                    // vector-memory operations per tile fetch
+constexpr int kTbPassLanes = 63;                  // lanes 0..62 decode (lane masks are built as (1 << n) - 1, n <= 63)
 
 __device__ __forceinline__ void tb_wait_vm(int n_after) {
     // wait until at most n_after vector-memory operations are outstanding (rounded down to a value that
@@ -372,68 +383,94 @@ __device__ __forceinline__ void tb_wait_vm(int n_after) {
 
 #define PSA_LIKELY(x) __builtin_expect(!!(x), 1)
 #define PSA_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#define PSA_SGPR(x) __builtin_amdgcn_readfirstlane(x)
+// (mask & a) | (~mask & b), and a scalar minimum the compiler does not move to the vector unit
+__device__ __forceinline__ unsigned tb_bfi(unsigned mask, unsigned a, unsigned b) {
+    unsigned d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ unsigned tb_uminu(unsigned a, unsigned b) {
+    unsigned d;
+    asm("s_min_u32 %0, %1, %2" : "=s"(d) : "s"(a), "s"(b) : "scc");
+    return d;
+}
+__device__ __forceinline__ int tb_smin(int a, int b) {
+    int d;
+    asm("s_min_i32 %0, %1, %2" : "=s"(d) : "s"(a), "s"(b) : "scc");
+    return d;
+}
 
 __device__ __forceinline__ void tb_walk(const TraceArgs& p) {
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[kTbSlots * kTbSlotBytes];
+    __shared__ __attribute__((aligned(1024))) uint8_t lds[kTbLdsBytes];
     const int lane = threadIdx.x;
-    int i = __builtin_amdgcn_readfirstlane((int)p.state[0]);
-    int j = __builtin_amdgcn_readfirstlane((int)p.state[1]);
-    int k = __builtin_amdgcn_readfirstlane((int)p.state[2]);
+    int i = PSA_SGPR((int)p.state[0]);
+    int j = PSA_SGPR((int)p.state[1]);
+    int k = PSA_SGPR((int)p.state[2]);
     const int c0 = (int)p.c0;
     if (p.start_triple) {
-        const int t1 = __builtin_amdgcn_readfirstlane(p.start_triple[0]), t2 = __builtin_amdgcn_readfirstlane(p.start_triple[1]),
-                  t3 = __builtin_amdgcn_readfirstlane(p.start_triple[2]);
+        const int t1 = PSA_SGPR(p.start_triple[0]), t2 = PSA_SGPR(p.start_triple[1]), t3 = PSA_SGPR(p.start_triple[2]);
         i = (int)p.n; j = c0 + p.W;
         k = (t1 >= t2 && t1 >= t3) ? 1 : (t2 >= t3 ? 2 : 3);
     }
-    const int Q = p.Q;
+    const int Q = p.Q, W = p.W, nrows = (int)p.n;
     const int rmin = (int)p.row_min;
     const int cap = (int)(p.cap < 0x1fffff00 ? p.cap : 0x1fffff00);   // 4 * cap fits the buffer descriptor
     int len = 0, done = 0, err = 0, bad = 0;
-    int my_tile = -1, my_ops = 0;          // lanes 0..15: directory of the LDS slots (tile id, op count after its fetch)
-    int victim = 0, ops = 0, ops_done = 0; // ops: vector-memory instructions issued so far
-    const __amdgpu_buffer_rsrc_t rs_ai = __builtin_amdgcn_make_buffer_rsrc(p.out_ai, 0, cap * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_bj = __builtin_amdgcn_make_buffer_rsrc(p.out_bj, 0, cap * 4, 0x00020000);
-    int cur_T = -1, cur_slot = -1;         // the tile of the predecessor cell ...
-    int slotL = -1, slotU0 = -1, slotU1 = -1;   // ... and the tiles beside it that its passes read (all pinned: never a victim)
-    int cpi = 0, ahead = 0;                // prefetch cursor: a row on the walk's diagonal, tiles ahead
-    int n_iter = 0, n_miss = 0, n_tiles = 0, n_single = 0;
-    const long long tc0 = (long long)__builtin_readcyclecounter(), tw0 = (long long)wall_clock64();
-#ifdef PSA_TB_TIMING
-    long long tsec[4] = {0, 0, 0, 0}, tmark = tc0;
-#define TB_MARK(x) { const long long now_ = (long long)__builtin_readcyclecounter(); tsec[x] += now_ - tmark; tmark = now_; }
+    u64 badm = 0;                          // lanes whose decode check failed in a pass that used them
+    int vtag = -1, vops = 0;               // lanes 0..15: directory of the window (tile id, op count after its fetch)
+    int ops = 0, ops_done = 0;             // ops: vector-memory instructions issued so far
+    int rlo = 0x7fffffff, ulo = 0x7fffffff;   // its first row and step (the passes stay at or above both); maximum: none entered
+    int rowfloor1 = 0, ufloor = 0;         // a lane may decode a cell of row >= rowfloor1 and step >= ufloor
+    int cr = -1;                           // fetch cursor: a row ahead of the walk (its step: on the walk's diagonal)
+    int curA = 0x7fffffff, curB = 0x7fffffff, a_need = 0, a_new = 0, b_need = 0, b_new = 0;   // residue rings
+#ifdef PSA_TB_STATS
+    int n_iter = 0, n_miss = 0, n_tiles = 0, n_single = 0;   // (counters cost scalar registers the walk is short of)
+#define TB_STAT(x) x
 #else
-#define TB_MARK(x)
+#define TB_STAT(x)
 #endif
-    // source offset of this lane's 16 bytes in the fetch that fills rows 16 f .. 16 f + 15 of the LDS image
+    const long long tc0 = (long long)__builtin_readcyclecounter(), tw0 = (long long)wall_clock64();
+    // per-lane constants
+    const unsigned lane2h = (unsigned)(2 * lane) << 24;
+    const unsigned lane6 = (unsigned)lane << 6;
+    const int lane4 = lane * 4;
+    const int lane0m = lane == 0 ? -1 : 0;
+    // source offset of this lane's 16 bytes in the fetch that fills rows 16 f .. 16 f + 15 of a tile's LDS image
     // (f = 0..3 adds 256 f): the tile is stored [part][row][16]
     const int swz = (lane & 3) * 1024 + (lane >> 2) * 16;
 
-    auto lookup = [&](int T) -> int {
-        const unsigned long long m = __ballot(my_tile == T);
-        return m ? (int)__builtin_ctzll(m) : -1;
-    };
-    // fetch tile (strip, q) and its residues into the next slot that is not pinned; returns the slot
-    auto issue = [&](int strip, int q) -> int {
-        while (victim == cur_slot || victim == slotL || victim == slotU0 || victim == slotU1) victim = (victim + 1) & (kTbSlots - 1);
-        const int slot = victim;
-        const int T = strip * Q + q;
-        uint8_t* dst = tiles + slot * kTbSlotBytes;
+    auto slot_of = [&](int s, int g) -> int { return ((g & 3) << 2) | (s & 3); };
+    auto tile_id = [&](int s, int g) -> int { return s * Q + (g - s); };
+    auto lds_of = [&](int row, int uu) -> int { return ((uu & 63) | ((row & 255) << 6) | (((uu >> 6) & 3) << 14)); };
+    // fetch tile (s, g) into its slot of the window
+    auto issue = [&](int s, int g, int slot, int T) {
+        uint8_t* dst = lds + kTbCodes + (slot >> 2) * kTbPlaneBytes + (slot & 3) * 4096;
         const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)(p.codes + (long long)T * kTileBytes), 0, kTileBytes, 0x00020000);
         // (the 256 f goes into the scalar offset: an immediate offset would also move the LDS address)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void*)(dst), 16, swz, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void*)(dst + 1024), 16, swz, 256, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void*)(dst + 2048), 16, swz, 512, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rt, (__attribute__((address_space(3))) void*)(dst + 3072), 16, swz, 768, 0, 0);
-        // residues (lanes past the 64 / 128 bytes are out of the descriptor's range: nothing is read for them)
-        const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + 64 * (long long)strip), 0, 64, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + (64 * (long long)q - 64)), 0, 128, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(dst + kTbA), 4, 4 * lane, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(dst + kTbB), 4, 4 * lane, 0, 0, 0);
         ops += kTbFetchOps;
-        if (lane == slot) { my_tile = T; my_ops = ops; }
-        victim = (victim + 1) & (kTbSlots - 1);
-        return slot;
+        // (value and lane select are both scalar: the lane select goes through m0)
+        asm volatile("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+                     : "+v"(vtag), "+v"(vops) : "s"(T), "s"(ops), "s"(slot) : "m0");
+    };
+    // 256 residues of A (rows 256 blk ..) / B (stripe columns 256 blk ..) into their ring; lanes past the end of
+    // the sequence are out of the descriptor's range and bring zeros (the range is rounded up to whole dwords -- a
+    // dword that straddles the end would be dropped whole --: the sequence buffers carry kSeqPad bytes of padding)
+    auto issue_a = [&](int blk) {
+        const int left = nrows - 256 * blk;
+        const __amdgpu_buffer_rsrc_t ra_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + 256 * (long long)blk), 0, left < 256 ? ((left + 3) & ~3) : 256, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (__attribute__((address_space(3))) void*)(lds + kTbRingA + 256 * (blk & 3)), 4, lane4, 0, 0, 0);
+        ++ops;
+    };
+    auto issue_b = [&](int blk) {
+        const int left = W - 256 * blk;
+        const __amdgpu_buffer_rsrc_t rb_ = __builtin_amdgcn_make_buffer_rsrc((void*)(p.b + 256 * (long long)blk), 0, left < 256 ? ((left + 3) & ~3) : 256, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (__attribute__((address_space(3))) void*)(lds + kTbRingB + 256 * (blk & 3)), 4, lane4, 0, 0, 0);
+        ++ops;
     };
     // every fetch up to operation number sq has landed
     auto landed_upto = [&](int sq) {
@@ -443,45 +480,71 @@ __device__ __forceinline__ void tb_walk(const TraceArgs& p) {
             __builtin_amdgcn_s_barrier();   // single wave: orders the LDS reads that follow behind the wait
         }
     };
-    // slot of tile (strip, q), fetched if need be, and landed
-    auto ensure = [&](int strip, int q) -> int {
-        int slot = lookup(strip * Q + q);
-        if (slot < 0) { ++n_miss; slot = issue(strip, q); }
-        landed_upto(__builtin_amdgcn_readlane(my_ops, slot));
-        return slot;
+    const __amdgpu_buffer_rsrc_t rs_ai = __builtin_amdgcn_make_buffer_rsrc(p.out_ai, 0, cap * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bj = __builtin_amdgcn_make_buffer_rsrc(p.out_bj, 0, cap * 4, 0x00020000);
+    auto put1 = [&](int va, int vb) {   // one step, from lane 0
+        const int off = lane == 0 ? 4 * len : -1;
+        __builtin_amdgcn_raw_buffer_store_b32(va, rs_ai, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(vb, rs_bj, off, 0, 0);
+        ops += 2;
     };
     // ---- one cell at a time (wave-uniform), any neighbour source: used next to boundaries only ----
     auto code_at = [&](int ci, int cj) -> unsigned {
-        const int st = (ci - 1) >> 6, ln = (ci - 1) & 63, ta = (cj - c0 - 1) + ln;
-        const int sl = ensure(st, ta >> 6);
-        return (unsigned)__builtin_amdgcn_readfirstlane((int)tiles[sl * kTbSlotBytes + ln * 64 + (ta & 63)]);
+        const int row = ci - 1, uu = (cj - c0 - 1) + row;
+        const int s = row >> 6, g = uu >> 6, slot = slot_of(s, g), T = tile_id(s, g);
+        if (__builtin_amdgcn_readlane(vtag, slot) != T) { TB_STAT(++n_miss); issue(s, g, slot, T); }
+        landed_upto(__builtin_amdgcn_readlane(vops, slot));
+        return (unsigned)PSA_SGPR((int)lds[kTbCodes + lds_of(row, uu)]);
     };
     auto D_at = [&](int ci, int cj) -> int {
         if (ci == 0 || cj == 0) return boundary_D(ci, cj);
-        if (cj == c0) return __builtin_amdgcn_readfirstlane(p.leftcol[ci].x);
-        if (ci == rmin) return __builtin_amdgcn_readfirstlane((int)((unsigned)p.toprow[cj - c0 - 1] >> 2));
+        if (cj == c0) return PSA_SGPR(p.leftcol[ci].x);
+        if (ci == rmin) return PSA_SGPR((int)((unsigned)p.toprow[cj - c0 - 1] >> 2));
         return (int)(code_at(ci, cj) >> 4);
     };
     auto Hn_at = [&](int ci, int cj) -> int {
         if (cj == 0) return boundary_Hn(ci, 0);
-        if (cj == c0) return __builtin_amdgcn_readfirstlane(p.leftcol[ci].y);
+        if (cj == c0) return PSA_SGPR(p.leftcol[ci].y);
         const unsigned c = code_at(ci, cj);
         return (int)((c >> 4) + ((c >> 2) & 3u));
     };
     auto Vn_at = [&](int ci, int cj) -> int {
         if (ci == 0) return boundary_Vn(0, cj);
         if (ci == rmin) {
-            const unsigned g = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)p.toprow[cj - c0 - 1]);
+            const unsigned g = (unsigned)PSA_SGPR((int)(unsigned)p.toprow[cj - c0 - 1]);
             return (int)((g >> 2) + (g & 3u));
         }
         const unsigned c = code_at(ci, cj);
         return (int)((c >> 4) + (c & 3u));
     };
 
+    // fetch tile (s, g) ahead of the walk unless it is in the window; false: its slot holds a tile the passes of
+    // the current tile T0 may read (T0 itself or T0 - 1 left; T0 - Q + 1 above or T0 - Q above left) -- later
+    auto fetch_ahead = [&](int s, int g, int T0) -> bool {
+        const int slot = slot_of(s, g), T = tile_id(s, g);
+        const int held = __builtin_amdgcn_readlane(vtag, slot);
+        if (held == T) return true;
+        if (tb_uminu((unsigned)(T0 - held), (unsigned)(T0 - Q + 1 - held)) <= 1u) return false;
+        issue(s, g, slot, T);
+        return true;
+    };
+    // the tiles beside tile (cs, cg) of the stripe that exist: left, above, above left
+    auto fetch_beside = [&](int cs, int cg, int T0) {
+        const int cq = cg - cs;
+        const int cup = ((0 - cs) & (rmin - (cs << 6))) >> 31;     // -1: the rows above strip cs have codes
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            // c = 0: left (block cq - 1 >= 0); 1: above (block cq + 1 < Q); 2: above left
+            const int ok = c == 0 ? (0 - cq) >> 31 : (c == 1 ? cup & ((cq + 1 - Q) >> 31) : cup);
+            if (ok) fetch_ahead(cs - (c != 0), cg - (c != 1), T0);
+        }
+    };
+
     for (;;) {
+        // ---- cold loop: the walk stands on cell (i, j) in table k ----
         if (i == 0 || j == 0) { done = 1; break; }
-        int pi = i - (k != 2), pj = j - (k != 3);   // the predecessor cell
-        if (PSA_UNLIKELY(pj <= c0 || pi <= rmin)) {
+        const int pi = i - (k != 2), pj = j - (k != 3);   // the predecessor cell
+        if (pj <= c0 || pi <= rmin) {
             if (c0 > 0 && pj <= c0) break;  // it belongs to the stripe on the left
             if (rmin > 0) break;            // ... or to the band of rows above
             // on the matrix boundary (pi == 0 or pj == 0)
@@ -489,169 +552,184 @@ __device__ __forceinline__ void tb_walk(const TraceArgs& p) {
             boundary_triple(pi, pj, t1, t2, t3);
             const int w = winner_plain(t1, t2, t3, k);
             if (len >= cap) { err = 1; break; }
-            {
-                const int off = lane == 0 ? 4 * len : -1;
-                __builtin_amdgcn_raw_buffer_store_b32((w == 2) ? -1 : (i - 1), rs_ai, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32((w == 3) ? -1 : (j - 1), rs_bj, off, 0, 0);
-                ops += 2;
-            }
+            put1((w == 2) ? -1 : (i - 1), (w == 3) ? -1 : (j - 1));
             ++len; i = pi; j = pj; k = w;
             continue;
         }
-        const int strip = (pi - 1) >> 6;
-        int ll = (pi - 1) & 63;                // row of the predecessor cell inside the strip
-        int jl = pj - c0 - 1;                  // its 0-based column inside the stripe
-        const int q = (jl + ll) >> 6;          // block of 64 wavefront steps
-        int tl = (jl + ll) & 63;               // its step inside the block
-        const int T = strip * Q + q;
-        const bool up_strip = strip >= 1 && 64 * strip > rmin;     // the row above the strip has codes
-        TB_MARK(0)
-        if (T != cur_T) {
-            ++n_tiles;
-            cur_slot = slotL = slotU0 = slotU1 = -1;   // (nothing is pinned while the walk is between tiles)
-            int slot = lookup(T);
-            if (PSA_UNLIKELY(slot < 0)) {
-                ++n_miss;
-                slot = issue(strip, q);
-                cpi = pi; ahead = 0;
-            } else {
-                ahead = ahead > 0 ? ahead - 1 : 0;
-                if (cpi > pi) { cpi = pi; ahead = 0; }
-            }
-            cur_T = T; cur_slot = slot;
-            // keep the fetches kTbAhead tiles ahead of the walk, along its current diagonal
-            const int diag = pi - pj;
-#pragma unroll 1
-            for (int rep = 0; rep < 2 && ahead < kTbAhead && cpi >= 1; ++rep) {
-                const int cj = cpi - diag;
-                if (cj < c0 + 1) { cpi = 0; break; }
-                const int bl = (cpi - 1) & 63;
-                const int bt = (cj - c0 - 1) + bl;
-                const int s1 = ((bt & 63) >> 1) + 1, s2 = bl + 1;
-                cpi -= s1 < s2 ? s1 : s2;          // first cell of the next tile on the diagonal
-                const int nj = cpi - diag;
-                if (cpi <= rmin || cpi < 1 || nj < c0 + 1) { cpi = 0; break; }   // (rows <= rmin: no codes at hand)
-                const int nl = (cpi - 1) & 63;
-                const int ns = (cpi - 1) >> 6, nq = ((nj - c0 - 1) + nl) >> 6;
-                if (lookup(ns * Q + nq) < 0) issue(ns, nq);
-                ++ahead;
-            }
-            // The tiles the passes may read beside this one -- the block in front of it, and the strip above at
-            // this block and the next -- if they are in the directory (they lie on or next to the diagonal): one
-            // wait covers all of them.
-            slotL = q >= 1 ? lookup(T - 1) : -1;
-            slotU0 = up_strip ? lookup(T - Q) : -1;
-            slotU1 = up_strip && q + 1 < Q ? lookup(T - Q + 1) : -1;
-            int sq = __builtin_amdgcn_readlane(my_ops, slot);
-            sq = max(sq, slotL >= 0 ? __builtin_amdgcn_readlane(my_ops, slotL & 15) : 0);
-            sq = max(sq, slotU0 >= 0 ? __builtin_amdgcn_readlane(my_ops, slotU0 & 15) : 0);
-            sq = max(sq, slotU1 >= 0 ? __builtin_amdgcn_readlane(my_ops, slotU1 & 15) : 0);
-            landed_upto(sq);
-        }
-        TB_MARK(1)
-        const int baseC = cur_slot * kTbSlotBytes;
-        const unsigned ra = tiles[baseC + kTbA + lane];              // residue of this lane's row
-        // ---- passes inside the tile: the predecessor cell is (row ll, step tl) of it ----
+        int r = pi - 1;                       // 0-based row of the predecessor cell
+        int u = (pj - c0 - 1) + r;            // its step: 0-based column inside the stripe + row
+        // (scalar state in plain integer arithmetic -- masks and sign bits, no booleans: the compiler turns uniform
+        // booleans into 64-bit lane masks at several instructions apiece.  nH / nV = -1: the walk stands in table 2 / 3)
+        int nH = -(int)(k == 2), nV = -(int)(k == 3);
+        // ---- hot loop: tile entries and passes, until a cell the passes cannot decode ----
         for (;;) {
-            // Lane ll's cell can be decoded from tiles when its left / upper-left neighbours are cells of this
-            // stripe (jl >= 1) and the row above has codes: inside the strip, or the last row of the strip
-            // above with both neighbours in one tile of it.  Lanes whose neighbours lie in a tile that is not in
-            // LDS are left out; if lane ll is one of them, the slow path below brings the tile in.
-            const int t0 = tl - 2 * ll;                               // step of the diagonal's cell in row 0
-            const int slotU = (t0 + 62 >= 64) ? slotU1 : slotU0;
-            const bool u_ok = slotU >= 0 && t0 >= -62 && jl - ll >= 1 && ((t0 + 63) & 63) != 0;
-            if (PSA_UNLIKELY(!(jl >= 1 && (ll >= 1 || u_ok) && (slotL >= 0 || tl >= 2)))) break;
-            TB_MARK(2)
-            ++n_iter;
-            const int bL = slotL * kTbSlotBytes + 64;
-            const int aU1 = slotU * kTbSlotBytes + 63 * 64 + ((t0 + 63) & 63);   // row 0's upper neighbours: row 63 of the strip above
-            const int aU2 = slotU * kTbSlotBytes + 63 * 64 + ((t0 + 62) & 63);
-            // lane l' looks at the cell of row l' on the diagonal through the predecessor: d = ll - l' moves on
-            const int d = ll - lane;
-            const int tt = tl - 2 * d;             // its step inside the block (negative: the block in front)
-            const bool valid = d >= 0 && jl - d >= 1 && tt >= (slotL >= 0 ? -62 : 2) && (lane >= 1 || u_ok);
-            const int tv = valid ? tt : tl, lv = valid ? lane : ll;   // (the others repeat lane ll's cell)
-            const int s0 = tv >= 0 ? baseC : bL, s1 = tv >= 1 ? baseC : bL, s2 = tv >= 2 ? baseC : bL;
-            const int rt = lv * 64 + tv;
-            const int au = lv == 0 ? aU1 : s1 + rt - 65;
-            const int ad = lv == 0 ? aU2 : s2 + rt - 66;
-            const unsigned cb = tiles[s0 + rt];
-            const unsigned cl = tiles[s1 + rt - 1];
-            const unsigned cu = tiles[au];
-            const unsigned cd = tiles[ad];
-            const unsigned rb = tiles[s0 + kTbB + 64 + (jl - ll - 64 * q) + lv];   // column jl - d of the window from 64 q - 64
+            if (((r - rlo) | (u - ulo)) < 0) {
+                // ---- enter the tile of the predecessor cell ----
+                TB_STAT(++n_tiles);
+                const int S0 = r >> 6, G0 = u >> 6;
+                rlo = S0 << 6; ulo = G0 << 6;
+                const int q0 = G0 - S0, T0 = S0 * Q + q0;
+                const int gs0 = (G0 & 3) << 2, gs1 = ((G0 - 1) & 3) << 2, ss0 = S0 & 3, ss1 = (S0 - 1) & 3;
+                const int slot0 = gs0 | ss0, slotL = gs1 | ss0, slotU0 = gs0 | ss1, slotU1 = gs1 | ss1;
+                if (PSA_UNLIKELY(__builtin_amdgcn_readlane(vtag, slot0) != T0)) {
+                    TB_STAT(++n_miss);
+                    issue(S0, G0, slot0, T0);
+                    cr = r;
+                }
+                cr = tb_smin(cr, r);                 // (-1: the cursor has reached the end of the codes)
+                int cu = 2 * cr + (u - 2 * r);       // the cursor follows the diagonal the walk is on now (gaps move the walk off the old one)
+                // residue rings: blocks of 256 rows / columns, the block in use, the one before it and one more
+                const int ablk = r >> 8, bblk = (u - r) >> 8;
+                if (PSA_UNLIKELY(ablk != curA)) {
+                    if (curA == 0x7fffffff) {
+                        issue_a(ablk);
+                        if (ablk >= 1) issue_a(ablk - 1);
+                        a_new = ops;
+                    }
+                    if (ablk >= 2) issue_a(ablk - 2);
+                    a_need = a_new; a_new = ops; curA = ablk;
+                }
+                if (PSA_UNLIKELY(bblk != curB)) {
+                    if (curB == 0x7fffffff) {
+                        issue_b(bblk);
+                        if (bblk >= 1) issue_b(bblk - 1);
+                        b_new = ops;
+                    }
+                    if (bblk >= 2) issue_b(bblk - 2);
+                    b_need = b_new; b_new = ops; curB = bblk;
+                }
+                // keep the fetches kTbAheadRows rows (about six tiles) ahead of the walk, along its current diagonal (2
+                // steps a row).  Where the diagonal leaves a tile within kTbCorner rows of its upper left corner the walk
+                // reads the tiles beside the corner as well (and gaps may move it into them): those are fetched too.
+#pragma unroll 1
+                for (int rep = 0; rep < 2; ++rep) {
+                    if ((cr | (kTbAheadRows - 1 - r + cr)) < 0) break;
+                    const int s1 = (cr & 63) + 1, s2 = ((cu & 63) >> 1) + 1;
+                    const int st = tb_smin(s1, s2);            // rows to the first cell of the next tile on the diagonal
+                    const int nr = cr - st, nu = cu - 2 * st;
+                    if (((nr - rmin) | (nu - nr)) < 0) { cr = -1; break; }   // (rows < rmin: no codes at hand; columns < 0: none)
+                    if (!fetch_ahead(nr >> 6, nu >> 6, T0)) break;   // (later)
+                    if (PSA_UNLIKELY((unsigned)(s1 - s2 + kTbCorner) <= 2u * kTbCorner)) fetch_beside(cr >> 6, cu >> 6, T0);
+                    cr = nr; cu = nu;
+                }
+                // The tiles the passes may read beside this one: the block in front of it, and the strip above at this
+                // block and the one in front.  Those in the window (they lie on or next to the diagonal) widen the
+                // rectangle the lanes of a pass may touch; a tile that does not exist (in front of the stripe's first
+                // block, behind its last) holds no cell a valid lane can name and counts as present.  A walk that enters
+                // near the tile's upper left corner without them (gaps moved it off the diagonal the fetches followed)
+                // asks for them now.  xL, xU0, xU1 = 0: the tile can be used.
+                const int up = ((0 - S0) & (rmin - rlo)) >> 31;          // -1: the rows above the strip have codes
+                const int mexL = (0 - q0) >> 31, mexU0 = up & ((q0 + 1 - Q) >> 31);   // -1: the tile exists
+                int xL = (__builtin_amdgcn_readlane(vtag, slotL) ^ (T0 - 1)) & mexL;
+                int xU0 = ((__builtin_amdgcn_readlane(vtag, slotU0) ^ (T0 - Q + 1)) & mexU0) | ~up;
+                int xU1 = (__builtin_amdgcn_readlane(vtag, slotU1) ^ (T0 - Q)) | ~up;
+                if (PSA_UNLIKELY((xL | ((xU0 | xU1) & up)) != 0)) {
+                    const int tr = (r & 63) + 1, tl = ((u & 63) >> 1) + 1;
+                    if ((unsigned)(tr - tl + kTbCorner) <= 2u * kTbCorner) {
+                        fetch_beside(S0, G0, 0x3ffffff0);
+                        xL = 0; xU0 = xU1 = ~up;
+                    }
+                }
+                const int oL = __builtin_amdgcn_readlane(vops, slotL) & mexL;
+                const int oU0 = __builtin_amdgcn_readlane(vops, slotU0) & mexU0;
+                const int oU1 = __builtin_amdgcn_readlane(vops, slotU1) & up;
+                // left: if xL == 0; above: if xU0 == 0, and with left only if xU1 == 0 as well
+                const int xU = xU0 | (xL == 0 ? xU1 : 0);
+                int sq = __builtin_amdgcn_readlane(vops, slot0);
+                ufloor = xL == 0 ? ulo - 62 : ulo + 2;
+                sq = max(sq, xL == 0 ? oL : 0);
+                const int rowfloor = xU == 0 ? rlo - 64 : rlo;
+                sq = max(sq, xU == 0 ? oU0 : 0);
+                sq = max(sq, (xL | xU) == 0 ? oU1 : 0);
+                rowfloor1 = max(rowfloor, rmin) + 1;
+                landed_upto(max(sq, max(a_need, b_need)));
+            }
+            // ---- one pass: the predecessor cell is (r, u) ----
+            // lane d decodes the cell d rows up the diagonal: row r - d, step u - 2 d, column (u - r) - d.  Its left
+            // and upper neighbours must be cells of this stripe with codes in the window: column >= 1, and the
+            // rectangle set when the tile was entered.
+            const int dmax = tb_smin(tb_smin(kTbPassLanes - 1, u - r - 1), tb_smin(r - rowfloor1, (u - ufloor) >> 1));
+            if (PSA_UNLIKELY(dmax < 0)) break;
+            TB_STAT(++n_iter);
+            const unsigned y0 = ((unsigned)u << 24) - lane2h;      // step of the lane's cell, modulo 256, in the top byte
+            const unsigned y1 = y0 - (1u << 24), y2 = y0 - (2u << 24);
+            const unsigned m0 = __builtin_amdgcn_perm(y0, y0, 0x0c0c0303u);   // step | step << 8
+            const unsigned m1 = __builtin_amdgcn_perm(y1, y1, 0x0c0c0303u);
+            const unsigned m2 = __builtin_amdgcn_perm(y2, y2, 0x0c0c0303u);
+            const unsigned w0 = ((unsigned)r << 6) - lane6, w1 = w0 - 64u;    // row << 6 (the merge keeps bits 6..13 only)
+            const unsigned cb = lds[kTbCodes + tb_bfi(0x3fc0u, w0, m0)];
+            const unsigned cl = lds[kTbCodes + tb_bfi(0x3fc0u, w0, m1)];
+            const unsigned cu_ = lds[kTbCodes + tb_bfi(0x3fc0u, w1, m1)];
+            const unsigned cd = lds[kTbCodes + tb_bfi(0x3fc0u, w1, m2)];
+            const unsigned ra = lds[kTbRingA + ((r - lane) & 1023)];
+            const unsigned rb = lds[kTbRingB + ((u - r - lane) & 1023)];
             const int x1 = (int)(cd >> 4) + (ra == rb ? kSubMatch : kSubMismatch);
             const int x2 = (int)((cl >> 4) + ((cl >> 2) & 3u));
-            const int x3 = (int)((cu >> 4) + (cu & 3u));
+            const int x3 = (int)((cu_ >> 4) + (cu_ & 3u));
             const int dp = (int)(cb >> 4);
             const int e1 = (dp - x1) & 15;
             int e2 = (dp - x2) & 15, e3 = (dp - x3) & 15;
-            const bool lbad = min(min(e1, e2), e3) != 0;
-            e2 -= (d == 0 && k == 2) ? 2 : 0;      // the first step leaves table k, the others table 1
-            e3 -= (d == 0 && k == 3) ? 2 : 0;
-            const unsigned long long mv = __ballot(valid);
-            const unsigned long long m1 = __ballot(valid && e1 <= e2 && e1 <= e3);
-            const unsigned long long m2 = __ballot(e2 <= e3);
-            const unsigned long long mb = __ballot(lbad);
-            const unsigned long long upto = (2ull << ll) - 1;           // lanes 0..ll (ll = 63: wraps to all ones)
-            const unsigned long long inv = ~m1 & upto;
-            const int lr = inv ? 63 - (int)__builtin_clzll(inv) : -1;   // lane of the first cell that is not a diagonal move
-            const int r = ll - lr;                                       // diagonal moves in this pass
-            const int has_g = lr >= 0 ? (int)((mv >> (lr & 63)) & 1ull) : 0;   // ... followed by a decoded non-diagonal step
-            const int w = ((m2 >> (lr & 63)) & 1ull) ? 2 : 3;
-            const int cnt = r + has_g;                                   // (>= 1: lane ll is valid)
-            bad |= (mb & upto & ~((1ull << (ll + 1 - cnt)) - 1)) ? 1 : 0;   // lanes ll - cnt + 1 .. ll were used
+            const u64 mb = __builtin_amdgcn_ballot_w64(min(min(e1, e2), e3) != 0);
+            const int nk2 = lane0m & nH, nk3 = lane0m & nV;   // the first step leaves table k, the others table 1
+            e2 += 2 * nk2;
+            e3 += 2 * nk3;
+            const u64 c12 = __builtin_amdgcn_ballot_w64(e1 <= e2);
+            const u64 c13 = __builtin_amdgcn_ballot_w64(e1 <= e3);
+            const u64 c23 = __builtin_amdgcn_ballot_w64(e2 <= e3);
+            const u64 stop = ~(c12 & c13) | (1ull << (dmax + 1));       // cells at which table 1 does not win; the lane past the last
+            const int run = (int)__builtin_ctzll(stop);                 // diagonal moves in this pass
+            const int has_g = (int)((unsigned)(run - dmax - 1) >> 31);  // the run ends in a decoded non-diagonal step ...
+            const int gH = has_g & (int)((unsigned)(c23 >> run) & 1u);  // ... into table 2
+            const int gV = has_g - gH;                                  // ... into table 3
+            const int cnt = run + has_g;                                // (>= 1)
+            badm |= mb & ((1ull << cnt) - 1);
             if (PSA_UNLIKELY(len + cnt > cap)) { err = 1; break; }
             {
-                // step d leaves cell (pi - d + 1, pj - d + 1) of table 1 -- step 0: cell (i, j) of table k
-                const int wd = d < r ? 1 : w;
-                const int off = (unsigned)d < (unsigned)cnt ? 4 * (len + d) : -1;   // -1: past the end, dropped
-                const int va = pi - d - ((d == 0 && k == 2) ? 1 : 0), vb = pj - d - ((d == 0 && k == 3) ? 1 : 0);
-                __builtin_amdgcn_raw_buffer_store_b32((wd == 2) ? -1 : va, rs_ai, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32((wd == 3) ? -1 : vb, rs_bj, off, 0, 0);
+                // step d leaves cell (row r - d + 1, ...) of table 1 -- step 0: cell (i, j) of table k; the lanes past
+                // the pass aim behind the end of the buffer and are dropped
+                const int gl2 = run | (gH - 1), gl3 = run | (gV - 1);   // lane of the gap step, or -1
+                const int va = (r + 1 - lane) + nk2, vb = (c0 + 1 + u - r - lane) + nk3;
+                const int off = lane < cnt ? 4 * len + lane4 : -1;
+                __builtin_amdgcn_raw_buffer_store_b32(lane == gl2 ? -1 : va, rs_ai, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(lane == gl3 ? -1 : vb, rs_bj, off, 0, 0);
                 ops += 2;
             }
             len += cnt;
-            // the walk now stands on the cell its last step reached, in the table that step named
-            const int di = r + (has_g & (w != 2)), dj = r + (has_g & (w != 3));
-            k = has_g ? w : 1;
-            pi -= di; pj -= dj; ll -= di; jl -= dj; tl -= 2 * r + has_g;
-            TB_MARK(3)
-            if (!(ll >= 0 && tl >= 0 && jl >= 0)) break;
+            // the walk now stands on the cell its last step reached, in the table that step named; the new
+            // predecessor cell is inside the rectangle (its row and column were a valid lane's, or one less)
+            nH = -gH; nV = -gV;
+            r -= run + gV;
+            u -= 2 * run + has_g;
         }
-        if (PSA_UNLIKELY(err)) break;
-        i = pi + (k != 2); j = pj + (k != 3);
-        if (PSA_UNLIKELY(ll >= 0 && tl >= 0 && jl >= 0)) {
-            // the pass loop stopped in front of a cell it cannot decode: a neighbour lies on a boundary, the
-            // two upper ones lie in different tiles, or a tile is not in LDS.  One cell, wave-uniform.
-            ++n_single;
-            const unsigned cb = (unsigned)__builtin_amdgcn_readfirstlane((int)tiles[baseC + ll * 64 + tl]);
-            const unsigned ras = (unsigned)__builtin_amdgcn_readlane((int)ra, ll);
-            const unsigned rb = (unsigned)__builtin_amdgcn_readfirstlane((int)tiles[baseC + kTbB + 64 + jl - 64 * q]);
-            const int x1 = D_at(pi - 1, pj - 1) + (ras == rb ? kSubMatch : kSubMismatch);
-            const int x2 = Hn_at(pi, pj - 1);
-            const int x3 = Vn_at(pi - 1, pj);
+        if (err) break;
+        k = 1 - nH - 2 * nV;
+        const int qi = r + 1, qj = c0 + 1 + (u - r);   // the predecessor cell now
+        i = qi + (k != 2); j = qj + (k != 3);
+        {
+            // the passes stopped in front of a cell they cannot decode: a neighbour lies on a boundary or in a
+            // tile that is not in the window.  One cell, wave-uniform.
+            TB_STAT(++n_single);
+            const unsigned cb = (unsigned)PSA_SGPR((int)lds[kTbCodes + lds_of(r, u)]);
+            const unsigned ras = (unsigned)PSA_SGPR((int)lds[kTbRingA + (r & 1023)]);
+            const unsigned rbs = (unsigned)PSA_SGPR((int)lds[kTbRingB + ((u - r) & 1023)]);
+            const int x1 = D_at(qi - 1, qj - 1) + (ras == rbs ? kSubMatch : kSubMismatch);
+            const int x2 = Hn_at(qi, qj - 1);
+            const int x3 = Vn_at(qi - 1, qj);
             const int w = winner_mod16((int)(cb >> 4), x1 & 15, x2 & 15, x3 & 15, k, &bad);
             if (len >= cap) { err = 1; break; }
-            {
-                const int off = lane == 0 ? 4 * len : -1;
-                __builtin_amdgcn_raw_buffer_store_b32((w == 2) ? -1 : (i - 1), rs_ai, off, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32((w == 3) ? -1 : (j - 1), rs_bj, off, 0, 0);
-                ops += 2;
-            }
+            put1((w == 2) ? -1 : (i - 1), (w == 3) ? -1 : (j - 1));
             ++len;
-            i = pi; j = pj; k = w;
-            cur_T = -1;   // (the slow path may have replaced the tiles beside this one: look them up again)
+            i = qi; j = qj; k = w;
+            rlo = 0x7fffffff;   // (the neighbours' tiles may have joined the window: enter the tile again)
         }
     }
-    if (bad && !err) err = 2;
+    if ((bad || badm) && !err) err = 2;
     if (lane == 0) {
         p.state[0] = i; p.state[1] = j; p.state[2] = k; p.state[3] = done; p.state[4] = len; p.state[5] = err;
+#ifdef PSA_TB_STATS
         p.state[6] = ((long long)n_iter << 32) | (unsigned)n_tiles; p.state[7] = ((long long)n_single << 32) | (unsigned)n_miss;
-        p.state[8] = (long long)__builtin_readcyclecounter() - tc0; p.state[9] = (long long)wall_clock64() - tw0;
-#ifdef PSA_TB_TIMING
-        p.state[10] = (tsec[0] << 32) | (tsec[1] & 0xffffffffLL); p.state[11] = (tsec[2] << 32) | (tsec[3] & 0xffffffffLL);
 #endif
+        p.state[8] = (long long)__builtin_readcyclecounter() - tc0; p.state[9] = (long long)wall_clock64() - tw0;
     }
 }
 
