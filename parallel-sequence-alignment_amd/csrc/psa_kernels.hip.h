@@ -365,20 +365,37 @@ constexpr int kTbPassLanes = 63;                  // lanes 0..62 decode (lane ma
 
 __device__ __forceinline__ void tb_wait_vm(int n_after) {
     // wait until at most n_after vector-memory operations are outstanding (rounded down to a value that
-    // exists as an immediate here): everything issued before the n_after most recent ones is complete
-    if (n_after >= 12) {
-        if (n_after >= 32) {
-            if (n_after >= 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        } else if (n_after >= 18) {
-            if (n_after >= 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        } else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    } else if (n_after >= 6) {
-        if (n_after >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if (n_after >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // exists as an immediate here): everything issued before the n_after most recent ones is complete.
+    // (one block of assembly: the compiler's version of this decision tree ran to some 25 instructions)
+    asm volatile(
+        "s_cmp_lt_u32 %0, 12\n\t"
+        "s_cbranch_scc1 1f\n\t"
+        "s_cmp_lt_u32 %0, 24\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_cmp_lt_u32 %0, 40\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        "s_waitcnt vmcnt(40)\n\t"
+        "s_branch 9f\n"
+        "3:\n\t"
+        "s_waitcnt vmcnt(24)\n\t"
+        "s_branch 9f\n"
+        "2:\n\t"
+        "s_waitcnt vmcnt(12)\n\t"
+        "s_branch 9f\n"
+        "1:\n\t"
+        "s_cmp_lt_u32 %0, 6\n\t"
+        "s_cbranch_scc1 4f\n\t"
+        "s_waitcnt vmcnt(6)\n\t"
+        "s_branch 9f\n"
+        "4:\n\t"
+        "s_cmp_lt_u32 %0, 2\n\t"
+        "s_cbranch_scc1 5f\n\t"
+        "s_waitcnt vmcnt(2)\n\t"
+        "s_branch 9f\n"
+        "5:\n\t"
+        "s_waitcnt vmcnt(0)\n"
+        "9:\n"
+        :: "s"(n_after) : "scc", "memory");
 }
 
 #define PSA_LIKELY(x) __builtin_expect(!!(x), 1)
@@ -393,6 +410,11 @@ __device__ __forceinline__ unsigned tb_bfi(unsigned mask, unsigned a, unsigned b
 __device__ __forceinline__ unsigned tb_uminu(unsigned a, unsigned b) {
     unsigned d;
     asm("s_min_u32 %0, %1, %2" : "=s"(d) : "s"(a), "s"(b) : "scc");
+    return d;
+}
+__device__ __forceinline__ int tb_smax(int a, int b) {
+    int d;
+    asm("s_max_i32 %0, %1, %2" : "=s"(d) : "s"(a), "s"(b) : "scc");
     return d;
 }
 __device__ __forceinline__ int tb_smin(int a, int b) {
@@ -637,12 +659,12 @@ __device__ __forceinline__ void tb_walk(const TraceArgs& p) {
                 const int xU = xU0 | (xL == 0 ? xU1 : 0);
                 int sq = __builtin_amdgcn_readlane(vops, slot0);
                 ufloor = xL == 0 ? ulo - 62 : ulo + 2;
-                sq = max(sq, xL == 0 ? oL : 0);
+                sq = tb_smax(sq, xL == 0 ? oL : 0);
                 const int rowfloor = xU == 0 ? rlo - 64 : rlo;
-                sq = max(sq, xU == 0 ? oU0 : 0);
-                sq = max(sq, (xL | xU) == 0 ? oU1 : 0);
-                rowfloor1 = max(rowfloor, rmin) + 1;
-                landed_upto(max(sq, max(a_need, b_need)));
+                sq = tb_smax(sq, xU == 0 ? oU0 : 0);
+                sq = tb_smax(sq, (xL | xU) == 0 ? oU1 : 0);
+                rowfloor1 = tb_smax(rowfloor, rmin) + 1;
+                landed_upto(tb_smax(sq, tb_smax(a_need, b_need)));
             }
             // ---- one pass: the predecessor cell is (r, u) ----
             // lane d decodes the cell d rows up the diagonal: row r - d, step u - 2 d, column (u - r) - d.  Its left
