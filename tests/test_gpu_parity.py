@@ -73,6 +73,33 @@ def test_random_vs_oracle_tile_edges(alpha):
         assert psa_amd.score(a, b, 1) == sc
 
 
+def test_block_indel_walks():
+    """Conserved blocks separated by alternating long insertions in A and in B: the walk alternates diagonal
+    runs with horizontal and vertical runs of 100-170 cells, which moves it through the traceback's tile
+    window in every direction (tiles revisited through another slot, fetch cursor off the diagonal,
+    tiles beside corners)."""
+    rng = np.random.default_rng(4242)
+    for blocks, lo, hi in ((24, 5, 90), (40, 30, 64), (12, 200, 400)):
+        xa, xb = [], []
+        for t in range(blocks):
+            blk = rng.integers(65, 85, int(rng.integers(lo, hi + 1))).astype(np.uint8)
+            xa.append(blk); xb.append(blk.copy())
+            ins = rng.integers(65, 85, int(rng.integers(100, 171))).astype(np.uint8)
+            (xa if t % 2 == 0 else xb).append(ins)
+        a = np.concatenate(xa); b = np.concatenate(xb)
+        # a few point mutations inside the blocks
+        for v in (a, b):
+            idx = rng.integers(0, len(v), len(v) // 50)
+            v[idx] = rng.integers(65, 85, len(idx)).astype(np.uint8)
+        sc, ai, bj = O.align(a, b)
+        for pp in (1, 3):
+            res = psa_amd.align(a, b, pp)
+            assert res.score == sc, (blocks, pp)
+            assert np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (blocks, pp)
+        res = psa_amd.align(a, b, 1, band_rows=512)
+        assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), blocks
+
+
 def test_row_chunks_and_stripes(monkeypatch):
     # several row chunks per stripe (chunk = 128 rows) and several stripes
     monkeypatch.setenv("PSA_CHUNK_ROWS", "128")
