@@ -29,3 +29,9 @@ u, c = np.unique(key[::4], return_counts=True)
 print("distinct (xcc,se,cu) used by workgroups:", len(u), "max WGs on one CU:", c.max())
 print("wait_in spins: med %d max %d; by wave %s ; wait_room: med %d max %d" % (np.median(d[:,5]), d[:,5].max(), [int(np.median(d[w::4,5])) for w in range(4)], np.median(d[:,6]), d[:,6].max()))
 print("first 12 strips:", [(int(x), round(float(s_), 1), round(float(e), 1)) for x, s_, e in zip(d[:12, 0], start[:12], end[:12])])
+big = np.argsort(endlag)[-12:]
+print("largest end lags (strip, us):", [(int(i_) + 1, round(float(endlag[i_]), 1)) for i_ in sorted(big)])
+print("end lag percentiles 50/90/99/99.9:", [round(float(np.percentile(endlag, q_)), 2) for q_ in (50, 90, 99, 99.9)])
+for i_ in sorted(big)[:4]:
+    lo = max(0, i_ - 3)
+    print("around strip %d:" % (i_ + 1), [(int(d[x, 0]), round(float(start[x]), 1), round(float(end[x]), 1), int(d[x, 5]), int(xcc[x])) for x in range(lo, min(len(d), i_ + 6))])
