@@ -31,11 +31,16 @@ def measure(nq=2048, nt=256, L=512, reps=3, check=8, prewarm=True):
     lib = psa_amd.lib()
     stream = torch.cuda.current_stream().cuda_stream
 
+    # launches of at most 2^22 pairs (about 0.3 s each): a kernel that runs for half a minute holds the
+    # GPU's queue against everything else and reads as a stall in a kernel trace
+    per_launch = 1 << 22
+
     def run():
-        d_ctr.zero_()
-        rc = lib.psa_score_batch_dev(d_flat.data_ptr(), d_off.data_ptr(), d_pairs.data_ptr(), pairs.shape[0], L,
-                                     d_scores.data_ptr(), d_ctr.data_ptr(), stream)
-        assert rc == 0, psa_amd.lib().psa_last_error()
+        for p0 in range(0, pairs.shape[0], per_launch):
+            cnt = min(per_launch, pairs.shape[0] - p0)
+            rc = lib.psa_score_batch_dev(d_flat.data_ptr(), d_off.data_ptr(), d_pairs.data_ptr() + 8 * p0, cnt, L,
+                                         d_scores.data_ptr() + 4 * p0, d_ctr.data_ptr(), stream)
+            assert rc == 0, psa_amd.lib().psa_last_error()
     if prewarm:
         run()
     torch.cuda.synchronize()
@@ -44,7 +49,7 @@ def measure(nq=2048, nt=256, L=512, reps=3, check=8, prewarm=True):
         run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    out = {"pairs": int(pairs.shape[0]), "residues": L, "ms": dt * 1e3,
+    out = {"pairs": int(pairs.shape[0]), "residues": L, "pairs_per_launch": int(min(per_launch, pairs.shape[0])), "ms": dt * 1e3,
            "gcups": pairs.shape[0] * float(L) * L / dt / 1e9}
     if check:
         import oracle_lib as O
