@@ -554,6 +554,25 @@ __device__ __forceinline__ bool run_steady_out(StripCtx<CODES>& c, FillLds& lds,
     return run_steady<CODES, IN, kOutNone>(c, lds, p, lo, hi);
 }
 
+// The capturing tail (lanes leave on the right and keep their values at column W-1), compiled per role for
+// the roles nearly every strip has.  A strip trails the one above by a fixed number of STEPS, so the time
+// between their ends is that number times the duration of a step in the section they end in: a tail that
+// decides its role at run time (2-3 x the instructions per block) cost stripes with a right boundary a third
+// of the whole fill.
+template <bool CODES, int IN, int OUT>
+__device__ __forceinline__ bool run_tail(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
+    for (int sb = lo; sb < hi; ++sb)
+        if (!run_superblock<CODES, kTail, IN, OUT>(c, lds, p, sb)) return false;
+    return true;
+}
+template <bool CODES>
+__device__ __forceinline__ bool run_tail_roles(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
+    if (c.from_lds && c.to_lds) return run_tail<CODES, kInLds, kOutLds>(c, lds, p, lo, hi);
+    if (c.from_lds && c.to_hbm) return run_tail<CODES, kInLds, kOutHbm>(c, lds, p, lo, hi);
+    if (!c.from_lds && !c.top_analytic && c.to_lds) return run_tail<CODES, kInHbm, kOutLds>(c, lds, p, lo, hi);
+    return run_tail<CODES, kAny, kAny>(c, lds, p, lo, hi);
+}
+
 template <bool CODES>
 // One workgroup per CU, one wavefront per SIMD: every strip is a link of one dependency chain, so
 // two workgroups sharing a CU (each at half speed) would hold up every strip behind them.  The
@@ -729,8 +748,7 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
         else if (c.top_analytic) ok = run_steady_out<CODES, kInTop>(c, lds, p, 0, fast_hi);
         else ok = run_steady_out<CODES, kInHbm>(c, lds, p, 0, fast_hi);
         if (!ok) return;
-        for (int sb = fast_hi; sb < p.Q; ++sb)
-            if (!run_superblock<CODES, kTail, kAny, kAny>(c, lds, p, sb)) return;
+        if (!run_tail_roles<CODES>(c, lds, p, fast_hi, p.Q)) return;
     } else {
         for (int sb = 0; sb < p.Q; ++sb)
             if (!run_superblock<CODES, kGeneric, kAny, kAny>(c, lds, p, sb)) return;

@@ -710,8 +710,10 @@ int run_stripes(StripeSet& set, int32_t triple[3]) {
             groups[j] = groups_of(jobs[j]);
             total += groups[j];
             // stripe j's group r can start once stripe j-1's group r is through: about (W + 64) steps, while
-            // groups of one stripe start about 4 x 90 steps apart
-            delay[j] = j ? delay[j - 1] + (unsigned)((set.st[g - 1]->W + 64 + 359) / 360) + 1 : 0;
+            // groups of one stripe start some 400 steps apart; a stripe that draws its tickets a little early
+            // (600 steps per ticket of delay, swept: PSA_STRIPE_SKEW_STEPS) waits less than one that draws them late
+            static const int skew_steps = [] { const char* e = getenv("PSA_STRIPE_SKEW_STEPS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 600; }();
+            delay[j] = j ? delay[j - 1] + (unsigned)((set.st[g - 1]->W + 64 + skew_steps - 1) / skew_steps) + 1 : 0;
         }
         const uint32_t* order_dev = nullptr;
         if (nj > 1) {
