@@ -15,6 +15,7 @@
 
 #include "psa_fill_v2.hip.h"
 #include "psa_batch.hip.h"
+#include "psa_trace2.hip.h"
 
 namespace {
 
@@ -456,7 +457,8 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     {
         const char* force = getenv("PSA_TRACEBACK_KERNEL");
         if ((force && !strcmp(force, "v1")) || !walk_fits32(s, ta.Q)) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
-        else hipLaunchKernelGGL(psa::traceback_wave, dim3(1), dim3(64), 0, st, ta);
+        else if (force && !strcmp(force, "wave1")) hipLaunchKernelGGL(psa::traceback_wave, dim3(1), dim3(64), 0, st, ta);
+        else hipLaunchKernelGGL(psa::traceback_pair, dim3(1), dim3(128), 0, st, ta);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[3], st));
@@ -466,9 +468,11 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     if (getenv("PSA_TRACE_STATS")) {
         fprintf(stderr, "traceback: len %lld passes %lld tiles %lld single-cell steps %lld misses %lld\n", (long long)state[4],
                 (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)(state[7] >> 32), (long long)(state[7] & 0xffffffff));
-        fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld (the counts above need a -DPSA_TB_STATS build)\n", (long long)state[8], (long long)state[9]);
+        fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld (the counts above need a -DPSA_TB_STATS build; fetcher: blocked %lld rounds %lld operations %lld)\n", (long long)state[8], (long long)state[9],
+                (long long)(state[10] >> 32), (long long)(state[10] & 0xffffffff), (long long)state[11]);
     }
     if (state[5] == 2) return fail(PSA_E_KERNEL, "traceback: winner codes failed the decode check (values that cannot belong to one cell)");
+    if (state[5] == 3) return fail(PSA_E_KERNEL, "traceback: the walk waited in vain for a code tile (fetching wavefront stalled)");
     if (state[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow");
     const int64_t got = state[4];
     if (*len_io + got > cap) return fail(PSA_E_ARG, "psa_stripe_traceback: output capacity %lld too small", (long long)cap);
@@ -1090,7 +1094,9 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         }
         tb.njobs = nt;
         if (nt > 0) {
-            hipLaunchKernelGGL(psa::traceback_wave_many, dim3(nt), dim3(64), 0, st, tb);
+            const char* force = getenv("PSA_TRACEBACK_KERNEL");
+            if (force && !strcmp(force, "wave1")) hipLaunchKernelGGL(psa::traceback_wave_many, dim3(nt), dim3(64), 0, st, tb);
+            else hipLaunchKernelGGL(psa::traceback_pair_many, dim3(nt), dim3(128), 0, st, tb);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1143,6 +1149,7 @@ int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_ou
     if (n > 0 && m > 0) {
         const int64_t* stt = e->h_state + 16 * slot;
         if (stt[5] == 2) return fail(PSA_E_KERNEL, "traceback: winner codes failed the decode check (slot %d)", slot);
+        if (stt[5] == 3) return fail(PSA_E_KERNEL, "traceback: the walk waited in vain for a code tile (slot %d)", slot);
         if (stt[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow (slot %d)", slot);
         if (!stt[3]) return fail(PSA_E_KERNEL, "traceback: the walk stopped before the matrix boundary (slot %d)", slot);
         len = stt[4];

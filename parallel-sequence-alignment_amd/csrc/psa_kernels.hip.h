@@ -358,7 +358,10 @@ constexpr int kTbRingA = 0;                       // A[row & 1023]
 constexpr int kTbRingB = 1024;                    // B[column & 1023]
 constexpr int kTbCodes = 2048;                    // (the rings come first: every address fits the 16-bit offset field)
 constexpr int kTbLdsBytes = kTbCodes + kTbCodeBytes;
-constexpr int kTbCorner = 4;                      // a diagonal that leaves a tile within this many rows of its corner: fetch the tiles beside it too
+#ifndef PSA_TB_CORNER
+#define PSA_TB_CORNER 4
+#endif
+constexpr int kTbCorner = PSA_TB_CORNER;                      // a diagonal that leaves a tile within this many rows of its corner: fetch the tiles beside it too
 constexpr int kTbAheadRows = 128;                 // the fetches run this many rows (about six tiles) ahead; the window is four strips tall
 constexpr int kTbFetchOps = 4;                    // vector-memory operations per tile fetch
 constexpr int kTbPassLanes = 63;                  // lanes 0..62 decode (lane masks are built as (1 << n) - 1, n <= 63)
