@@ -247,8 +247,10 @@ __device__ __forceinline__ void t2_walker(const TraceArgs& p, uint8_t* lds) {
         int r = pi - 1;
         int u = (pj - c0 - 1) + r;
         int nH = -(int)(k == 2), nV = -(int)(k == 3);
+        int fresh = 0;     // 1: the tags were read for this very cell
         for (;;) {
             if (((r - rlo) | (u - ulo)) < 0) {
+                fresh = 1;
                 // ---- enter the tile of the predecessor cell: tell the fetcher, read what has landed ----
                 TB_STAT(++n_tiles);
                 ++seq;
@@ -292,7 +294,12 @@ __device__ __forceinline__ void t2_walker(const TraceArgs& p, uint8_t* lds) {
             }
             // ---- one pass (as in tb_walk) ----
             const int dmax = tb_smin(tb_smin(kTbPassLanes - 1, u - r - 1), tb_smin(r - rowfloor1, (u - ufloor) >> 1));
-            if (PSA_UNLIKELY(dmax < 0)) break;
+            if (PSA_UNLIKELY(dmax < 0)) {
+                if (fresh) break;
+                rlo = 0x7fffffff;       // what this cell needs may have landed since the tile was entered: look again
+                continue;
+            }
+            fresh = 0;
             TB_STAT(++n_iter);
             const unsigned y0 = ((unsigned)u << 24) - lane2h;
             const unsigned y1 = y0 - (1u << 24), y2 = y0 - (2u << 24);
@@ -347,7 +354,18 @@ __device__ __forceinline__ void t2_walker(const TraceArgs& p, uint8_t* lds) {
             // a cell the passes cannot decode: one cell, from global memory (every neighbour source: boundary,
             // left boundary column, row above a band, code byte)
             TB_STAT(++n_single);
-            const int w = PSA_SGPR(tb_winner(p, qi, qj, k, &bad));
+            int w;
+            if (PSA_LIKELY(qi - 1 > rmin && qi - 1 >= 1 && qj - 1 > c0)) {
+                // all three neighbours are cells of this stripe with codes: four independent loads, one wait
+                const unsigned cP = tb_code(p, qi, qj), cD = tb_code(p, qi - 1, qj - 1), cL = tb_code(p, qi, qj - 1), cU = tb_code(p, qi - 1, qj);
+                const unsigned ras = lds[kTbRingA + (r & 1023)], rbs = lds[kTbRingB + ((u - r) & 1023)];
+                const int x1 = (int)(cD >> 4) + (ras == rbs ? kSubMatch : kSubMismatch);
+                const int x2 = (int)((cL >> 4) + ((cL >> 2) & 3u));
+                const int x3 = (int)((cU >> 4) + (cU & 3u));
+                w = PSA_SGPR(winner_mod16((int)(cP >> 4), x1 & 15, x2 & 15, x3 & 15, k, &bad));
+            } else {
+                w = PSA_SGPR(tb_winner(p, qi, qj, k, &bad));
+            }
             if (len >= cap) { err = 1; break; }
             put1((w == 2) ? -1 : (i - 1), (w == 3) ? -1 : (j - 1));
             ++len;
