@@ -246,6 +246,23 @@ def test_batch_scores_match_oracle():
         assert got[idx] == O.score(prot[i], prot[j])
 
 
+def test_batch_oversize_second_sequences_among_short_pairs():
+    """Pairs whose second sequence exceeds the batch kernel's LDS row buffer (1024) are skipped by the kernel and
+    sent through psa_score; the ordinary pairs of the same launch must not be disturbed by them."""
+    rng = np.random.default_rng(77)
+    seqs = [rng.integers(65, 85, ln).astype(np.uint8) for ln in (1500, 3000, 8000)]
+    seqs += [rng.integers(65, 85, int(rng.integers(50, 600))).astype(np.uint8) for _ in range(40)]
+    pairs = [(i, j) for i in range(3, 43) for j in range(3, 43, 5)]          # short x short
+    pairs += [(i, j) for i in range(3, 43, 3) for j in range(3)]             # short x oversize second sequence
+    pairs += [(j, i) for i in range(3, 43, 7) for j in range(3)]             # oversize first sequence
+    pairs += [(0, 1), (1, 2), (2, 0)]
+    order = rng.permutation(len(pairs))
+    pairs = [pairs[k] for k in order]
+    got = psa_amd.score_batch(seqs, pairs)
+    for (i, j), g in zip(pairs, got):
+        assert g == O.score(seqs[i], seqs[j]), (len(seqs[i]), len(seqs[j]))
+
+
 def test_alignments_in_flight_concurrently():
     """Several whole-pair alignments at once (a host thread each, the library's per-call streams),
     as the bench's throughput mode does: results stay those of the oracle."""
@@ -271,17 +288,21 @@ def test_alignments_in_flight_concurrently():
 
 
 def test_traceback_kernels_agree(monkeypatch):
-    """The wave-cooperative walk and the single-lane walk read the same packed codes."""
+    """The two-wave walk (default), the single-wave walk and the single-lane walk read the same codes."""
     rng = np.random.default_rng(12)
     a = rng.integers(65, 69, 2500).astype(np.uint8)
     b = rng.integers(65, 69, 2700).astype(np.uint8)
     r1 = psa_amd.align(a, b, 1)
+    monkeypatch.setenv("PSA_TRACEBACK_KERNEL", "wave1")    # one wavefront that walks and fetches
+    rw = psa_amd.align(a, b, 1)
+    rw3 = psa_amd.align(a, b, 3)
+    rwb = psa_amd.align(a, b, 1, band_rows=512)
     monkeypatch.setenv("PSA_TRACEBACK_KERNEL", "v1")
     r2 = psa_amd.align(a, b, 1)
     monkeypatch.setenv("PSA_FILL_KERNEL", "v1")
     r3 = psa_amd.align(a, b, 1)
     sc, ai, bj = O.align(a, b)
-    for r in (r1, r2, r3):
+    for r in (r1, rw, rw3, rwb, r2, r3):
         assert r.score == sc and np.array_equal(r.ai, ai) and np.array_equal(r.bj, bj)
 
 
