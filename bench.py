@@ -33,8 +33,15 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 VALU_PEAK_TOPS = 39.3216      # 256 CU x 64 int32 lanes/clk x 2.4 GHz (tools/valu_peak measures 38.8)
-OPS_PER_CELL_CODES = 25       # algorithmic int32 VALU ops per cell with winner codes
-OPS_PER_CELL_SCORE = 10       # score only
+# Algorithmic int32 VALU operations per cell.  SURVEY 8d priced the recurrence at 10 (score only) and
+# 25 (with winner bits: three compares and their packing per aggregate); with the one-byte winner code the
+# recurrence is 8 operations (two lane shifts, substitution add, two gap adds, max3, two max) and the code 3.
+# At the SURVEY's 25 the 8-pair launch would read 1.2 "of peak": the figures below use 11 and 8, and the
+# SURVEY's are kept beside them (frac_at_survey_ops) for comparison with round 1.
+OPS_PER_CELL_CODES = 11
+OPS_PER_CELL_SCORE = 8
+OPS_PER_CELL_BATCH = 10       # batch kernel: compares residues itself (v_cmp + v_cndmask) instead of a table byte
+SURVEY_OPS_CODES, SURVEY_OPS_SCORE = 25, 10
 HBM_PEAK_GBS = 8000.0
 PROFILE_DIR = os.path.join("profiles", "r2")
 
@@ -237,7 +244,7 @@ def single_gpu(args):
     achieved = per_launch_pairs * cells1 * OPS_PER_CELL_CODES / (fill_ms * 1e-3) / 1e12
     aggregate = cells1 * OPS_PER_CELL_CODES * args.steps / dt / 1e12
     grid = per_launch_pairs * ((n + 255) // 256)
-    traffic, traffic_src = pmc_traffic("fill_strips_v2<true>", grid * 256)
+    traffic, traffic_src = pmc_traffic("<true>(psa::FillBatch)", grid * 256)
 
     # ---- the same alignment alone on the GPU: latency of one pair, and the one-pair fill kernel ----
     one = psa_amd.Many(1, n, m, traceback=True)
@@ -268,16 +275,20 @@ def single_gpu(args):
                    "fill_launches_overlap": bool(args.overlap_fills), "host_threads": 1,
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
-        "roofline": {"bound": "valu", "kernel": "fill_strips_v2<true>: ONE launch filling %d pairs (winner codes on)" % per_launch_pairs,
+        "roofline": {"bound": "valu", "kernel": "fill_strips_v2_dense<true>: ONE launch filling %d pairs (winner codes on), two wavefronts per SIMD" % per_launch_pairs,
                      "achieved": achieved, "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
                      "ops_per_cell": OPS_PER_CELL_CODES, "cells_per_launch": per_launch_pairs * cells1,
-                     "valu_insts_per_cell_executed": pmc_valu_per_cell("fill_strips_v2<true>", grid * 256, per_launch_pairs * cells1),
+                     "frac_at_survey_ops": achieved / VALU_PEAK_TOPS * SURVEY_OPS_CODES / OPS_PER_CELL_CODES,
+                     "ops_note": "11 = 8 for the recurrence + 3 for the one-byte winner code; SURVEY 8d's 25 priced three "
+                                 "compares per aggregate, which this kernel does not do (frac_at_survey_ops keeps that scale)",
+                     "valu_insts_per_cell_executed": pmc_valu_per_cell("<true>(psa::FillBatch)", grid * 256, per_launch_pairs * cells1),
                      "kernel_ms": fill_ms, "launches_timed": len(full),
                      "kernel_ms_note": "HIP events around the fill launch on the engine's stream, every launch of the timed "
                                        "region; the other engine's walks (one wavefront per pair) run beside it",
                      "fill_gcups": per_launch_pairs * cells1 / (fill_ms * 1e-3) / 1e9,
                      "aggregate_achieved": aggregate, "aggregate_frac": aggregate / VALU_PEAK_TOPS,
                      "one_pair_alone": {"kernel_ms": fill1, "frac": cells1 * OPS_PER_CELL_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                        "frac_at_survey_ops": cells1 * SURVEY_OPS_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                                         "structural_ceiling": min(1.0, cells1 / ((n + m) * 65536.0))},
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (separate --pmc passes)",
                      "traffic_source": traffic_src,
@@ -312,7 +323,7 @@ def single_gpu(args):
         bench_batch.measure(nq=512, nt=256, L=512, reps=1, check=0)   # warm-up
         big = os.environ.get("PSA_BENCH_BATCH", "config5") == "config5"
         bb = bench_batch.measure(nq=100000 if big else 2048, nt=4096 if big else 256, L=512, reps=1 if big else 3, check=4, prewarm=not big)
-        bb["valu_frac"] = bb["gcups"] * OPS_PER_CELL_SCORE / 1e3 / VALU_PEAK_TOPS
+        bb["valu_frac"] = bb["gcups"] * OPS_PER_CELL_BATCH / 1e3 / VALU_PEAK_TOPS
         bb["note"] = ("BASELINE config 5 on one GPU: 100 000 synthetic 512-residue queries x a block of 4 096 targets, every "
                       "pair, score only, sequences and pair list resident in HBM (the full all-vs-all is 5e9 pairs: a "
                       "stated block of it, SURVEY 8d)") if big else "reduced block (PSA_BENCH_BATCH != config5)"

@@ -38,10 +38,12 @@ constexpr int kGranCols = PSA_GRAN_COLS;
 constexpr int kGDist = PSA_GDIST;  // granule requests run this many blocks ahead (1, 2 or 4)
 // Dynamic LDS a fill workgroup is launched with and never uses (see fill_strips_v2).  One pair alone: 96 KB, so that
 // neither a second fill workgroup nor a traceback walk (70 KB) fits on the CU beside it.  Several pairs in one
-// launch: 70 KB -- still no second fill workgroup (2 x 82 KB > 160 KB), but the walks of the previous batch
-// find room beside the fill of the next one (82 + 70 KB).
+// launch: the stripes of ONE pair 70 KB -- still no second fill workgroup (2 x 82 KB > 160 KB), but walks find
+// room beside it (82 + 70 KB); independent pairs (fill_strips_v2_dense) 16 KB: two workgroups per CU, limited by
+// their registers, and a walk's workgroup beside them where registers allow.
 constexpr int kKeepoutAloneBytes = 96 * 1024;
 constexpr int kKeepoutManyBytes = 70 * 1024;
+constexpr int kKeepoutDenseBytes = 16 * 1024;
 constexpr int kFrontWord = 32;  // control block: [0] ticket, [1] abort flag, [32] front (own cache line)
 constexpr int kNW = 4;         // strips (wavefronts) per workgroup
 constexpr int kRing = 256;     // LDS ring slots per strip boundary (8 bytes each)
@@ -573,11 +575,9 @@ __device__ __forceinline__ bool run_tail_roles(StripCtx<CODES>& c, FillLds& lds,
     return run_tail<CODES, kAny, kAny>(c, lds, p, lo, hi);
 }
 
+// The body of the fill kernels (two entry points below differ in their occupancy attribute only).
 template <bool CODES>
-// One workgroup per CU, one wavefront per SIMD: every strip is a link of one dependency chain, so
-// two workgroups sharing a CU (each at half speed) would hold up every strip behind them.  The
-// occupancy attribute makes the register budget 512 per wave and keeps a second workgroup out.
-__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WAVES_PER_EU, PSA_WAVES_PER_EU))) void fill_strips_v2(FillBatch B) {
+__device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
     __shared__ FillLds lds;
     __shared__ unsigned wg_ticket;
     // Dynamic LDS nobody uses (its size is chosen at the launch): with it a workgroup takes more than half
@@ -800,6 +800,24 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_WA
             }
         }
     }
+}
+
+// One pair (or the stripes of one pair) per launch: one workgroup per CU, one wavefront per SIMD.  Every strip is
+// a link of one dependency chain, so a second wavefront on a SIMD would hold up every strip behind the one it
+// shares issue slots with.  The occupancy attribute makes the register budget 512 per wave; the launch's
+// dynamic-LDS keep-out keeps a second workgroup off the CU.
+template <bool CODES>
+__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void fill_strips_v2(FillBatch B) {
+    fill_strips_body<CODES>(B);
+}
+// Independent pairs in one launch: the chains of different pairs do not wait for each other, and a lone
+// wavefront uses less than half of its SIMD's issue slots (one instruction per 4.7 cycles, 12.5 of 21 of them
+// VALU).  Two wavefronts per SIMD -- two workgroups per CU, 256 registers each -- interleave: the same code
+// fills 8 pairs in 18.0 ms instead of 23.4 (the register cap costs spills in the run-time-role paths and 2 % on
+// a lone pair, which is why the sparse kernel stays).
+template <bool CODES>
+__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fill_strips_v2_dense(FillBatch B) {
+    fill_strips_body<CODES>(B);
 }
 
 }  // namespace psa

@@ -341,7 +341,7 @@ unsigned groups_of(const psa::FillArgs2& j) {
 
 // One launch of fill_strips_v2 over up to kMaxJobs stripes.  order_dev: ticket -> job << 24 | group (null: one job).
 int launch_fill_v2(const psa::FillArgs2* jobs, int njobs, const uint32_t* order_dev, unsigned total_groups,
-                   unsigned* ticket_dev, bool with_codes, size_t keepout_bytes, hipStream_t st) {
+                   unsigned* ticket_dev, bool with_codes, size_t keepout_bytes, hipStream_t st, bool dense = false) {
     static bool attr_set[2] = {false, false};
     if (!attr_set[with_codes]) {   // dynamic LDS beyond 64 KB has to be allowed once per kernel
         if (with_codes) HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
@@ -352,7 +352,10 @@ int launch_fill_v2(const psa::FillArgs2* jobs, int njobs, const uint32_t* order_
     memset(&fb, 0, sizeof fb);
     for (int j = 0; j < njobs; ++j) fb.job[j] = jobs[j];
     fb.njobs = njobs; fb.order = order_dev; fb.ticket = ticket_dev;
-    if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
+    if (dense) {   // independent pairs: two workgroups per CU (PSA_FILL_DENSE=0: the one-wave-per-SIMD kernel)
+        if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2_dense<true>, dim3(total_groups), dim3(psa::kNW * 64), psa::kKeepoutDenseBytes, st, fb);
+        else hipLaunchKernelGGL(psa::fill_strips_v2_dense<false>, dim3(total_groups), dim3(psa::kNW * 64), psa::kKeepoutDenseBytes, st, fb);
+    } else if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
     else hipLaunchKernelGGL(psa::fill_strips_v2<false>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
     HIP_TRY(hipGetLastError());
     return PSA_OK;
@@ -1075,8 +1078,9 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         }
         HIP_TRY(hipMemsetAsync(e->ticket, 0, 256, st));
         HIP_TRY(hipEventRecord(e->ev[0], st));   // (the events bracket the fill launch itself)
+        static const bool dense_ok = [] { const char* v = getenv("PSA_FILL_DENSE"); return !(v && v[0] == '0'); }();
         if (int rc = launch_fill_v2(jobs, nj, order_dev, total, e->ticket, with_codes,
-                                    nj > 1 ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes, st)) return rc;
+                                    nj > 1 ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes, st, nj > 1 && dense_ok)) return rc;
     } else HIP_TRY(hipEventRecord(e->ev[0], st));
     HIP_TRY(hipEventRecord(e->ev[1], st));
     // the walks: one wavefront per pair, all in one launch, each starting from its pair's final pick
