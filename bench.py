@@ -49,11 +49,11 @@ PROFILE_DIR = os.path.join("profiles", "r2")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=0, help="rows per inter-GPU hand-off (N > 1, stripes); 0 = from the stripe width")
-    ap.add_argument("--slots", type=int, default=8, help="pairs per launch (1..8); two engines take turns")
+    ap.add_argument("--slots", type=int, default=16, help="pairs per launch (1..16); two engines take turns")
     ap.add_argument("--overlap-fills", action="store_true",
                     help="let the two engines' fill launches overlap (default: each fill launch alone on the chip)")
     ap.add_argument("--mode", choices=["pairs", "stripes"], default="pairs",
@@ -200,7 +200,7 @@ def single_gpu(args):
     a_dev = torch.from_numpy(a).cuda()
     b_dev = torch.from_numpy(b).cuda()
     torch.cuda.synchronize()
-    S = min(8, max(1, args.slots))
+    S = min(16, max(1, args.slots))
     engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(2)]
     serial = not args.overlap_fills
 

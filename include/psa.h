@@ -88,7 +88,7 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
                    int64_t* len_out);
 
 /* The engine behind it, for callers whose pairs are resident in device memory or who run their own
- * loop.  `slots` (1..8) pairs of up to n_cap x m_cap are in flight per launch; flags: PSA_F_TRACEBACK
+ * loop.  `slots` (1..16) pairs of up to n_cap x m_cap are in flight per launch; flags: PSA_F_TRACEBACK
  * for alignments, 0 for scores.  All device and pinned host buffers are allocated by create; the
  * other calls allocate nothing on the device (a changed set of pair sizes re-uploads a few KB of
  * ticket order).  An engine owns a stream; calls on one engine must not overlap, engines are independent.

@@ -66,7 +66,7 @@ struct FillArgs2 {
 // together they keep every CU busy, which one 2^16 pair alone cannot (its chain is n + m steps long
 // whatever the hardware).  A workgroup only ever waits for workgroups with lower tickets, which run
 // already or have finished: no assumption on dispatch order or residency.
-constexpr int kMaxJobs = 8;
+constexpr int kMaxJobs = 16;
 constexpr int kOrderJobShift = 24;   // order[t] = job << 24 | group
 struct FillBatch {
     FillArgs2 job[kMaxJobs];

@@ -1193,12 +1193,12 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
         n_cap = std::max(n_cap, n[k]); m_cap = std::max(m_cap, m[k]);
         if (want_al) { ai_out[k] = bj_out[k] = nullptr; len_out[k] = 0; }
     }
-    // slots per engine: what fits in half of the free device memory, at most 4 (two engines: 8 pairs in flight)
+    // slots per engine: what fits in half of the free device memory, at most 8 (two engines: 16 pairs in flight)
     psa_release_cache();
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double per_slot = (want_al ? (double)n_cap * (double)m_cap * 1.05 : 0.0) + 64.0 * (double)(n_cap + m_cap) + (1 << 20);
-    int slots = (int)std::min<double>(4.0, 0.5 * (double)free_b / (2.0 * per_slot));
+    int slots = (int)std::min<double>(8.0, 0.5 * (double)free_b / (2.0 * per_slot));
     slots = (int)std::min<int64_t>(slots, (npairs + 1) / 2);
     if (slots < 1) {
         // not even one pair per engine fits with its codes: one at a time through psa_align (linear space if need be)

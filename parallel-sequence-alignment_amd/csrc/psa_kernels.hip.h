@@ -249,7 +249,7 @@ struct TraceArgs {
     const int32_t* start_triple;   // not null: the walk starts at (n, c0 + W) in the table the final pick of this
                                    // triple names (simple.cpp:246-256) instead of at state[0..2]
 };
-constexpr int kMaxWalks = 8;
+constexpr int kMaxWalks = 16;
 struct TraceBatch {          // one wavefront (workgroup) per walk
     TraceArgs job[kMaxWalks];
     int njobs;
