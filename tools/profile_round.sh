@@ -14,7 +14,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/one -o one -- python3 $
 echo "slots 1 done"
 for P in "w WRITE_SIZE" "f FETCH_SIZE" "sq SQ_INSTS_VALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_BUSY_CYCLES" "act SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
   set -- $P; tag=$1; shift
-  timeout -s KILL 200 rocprofv3 --pmc "$@" -d $O/pmc_$tag -o pmc_$tag -- python3 $R/bench.py --steps 16 --warmup 0 --no-extra --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err
+  timeout -s KILL 200 rocprofv3 --pmc "$@" -d $O/pmc_$tag -o pmc_$tag -- python3 $R/bench.py --steps 32 --warmup 0 --no-extra --no-cpu-baseline > $O/pmc_$tag.json 2> $O/pmc_$tag.err
   echo "pmc $tag done"
 done
 cd $R
