@@ -201,6 +201,9 @@ def single_gpu(args):
     b_dev = torch.from_numpy(b).cuda()
     torch.cuda.synchronize()
     S = min(16, max(1, args.slots))
+    # (a slot holds n x m bytes of winner codes; two engines: keep a fifth of the device memory free)
+    free_b, _total_b = torch.cuda.mem_get_info()
+    S = max(1, min(S, int(0.8 * free_b / (2.0 * (float(n) * m * 1.05 + (64 << 20))))))
     engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(2)]
     serial = not args.overlap_fills
 
