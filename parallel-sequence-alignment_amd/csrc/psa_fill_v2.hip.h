@@ -119,7 +119,7 @@ __global__ void build_eqtab(const uint8_t* b, int W, const unsigned* meta, const
 struct __attribute__((aligned(128))) FillLds {
     int2 ring[kNW][kRing];       // ring[w]: input of wave w; slot s = (D of column s-65, V of column s-64)
     int2 stage[kNW][32];         // staging of a wave's last row on its way to HBM granules
-    int dummy[kNW][160];         // where lanes other than 63 drop their publish writes (8 bytes a lane and step; see out_base)
+    int dummy[kNW][320];         // where lanes other than 63 drop their publish writes (16 bytes a lane; see out_base)
     int dummy2[kNW][64];         // where lanes that own no counter drop their counter posts
     int prod[kNW];               // steps completed by the producer of ring[w]
     int cons[kNW];               // ring[w] slots below this number have been read
@@ -151,7 +151,7 @@ struct StripState {
 enum : int { kFast = 0, kHead = 1, kTail = 2, kGeneric = 3 };
 
 // One anti-diagonal step.  k = step inside the block (compile-time), pre = lane 0's inputs for
-// steps 2j, 2j+1 as (D of column-1, V of column) pairs, pa/pb = where this lane drops (D, V).
+// steps 2j, 2j+1 as (D of column-1, V of column) pairs, pa = where this lane drops the block's slots.
 // a + byte `sel` of w in one instruction (SDWA source select): the substitution score needs no extract
 __device__ __forceinline__ int add_byte(int a, unsigned w, int sel) {
     int r;
@@ -166,10 +166,11 @@ __device__ __forceinline__ int add_byte(int a, unsigned w, int sel) {
 
 template <bool CODES, int MODE>
 __device__ __forceinline__ void step16(const int k, StripState& S, const int4& pre, const unsigned mword,
-                                       int* pa, int* pb, const int t, const int lane, const int W,
+                                       int* pa, const int t, const int lane, const int W,
                                        const bool row_ok) {
     const int preD = (k & 1) ? pre.z : pre.x;
     const int preV = (k & 1) ? pre.w : pre.y;
+    const int Dm2 = S.D0, Vm1 = S.V;   // (even k) committed D of step k-2, V of step k-1: gone after this step
     const int x1 = add_byte(shift_down1(preD, (k & 1) ? S.D1 : S.D0), mword, k & 3);
     const int x3 = shift_down1(preV, S.V);
     const int x2 = S.H;
@@ -189,20 +190,13 @@ __device__ __forceinline__ void step16(const int k, StripState& S, const int4& p
         S.H = Hn;
         S.V = Vn;
     }
-    // publish (committed values): V of this step's column -> slot k+1, D -> slot k+2
-    if (CODES) {
-        // (the compiler pairs the two dwords into one ds_write2_b32 where it can; measured 5 % faster alone than the
-        // variant below in this kernel, whose register pairs cost it moves)
-        const int Dc = (k & 1) ? S.D1 : S.D0;
-        if (k + 1 < kBlk) pa[2 * (k + 1) + 1] = S.V; else pb[2 * (k + 1 - kBlk) + 1] = S.V;
-        if (k + 2 < kBlk) pa[2 * (k + 2)] = Dc; else pb[2 * (k + 2 - kBlk)] = Dc;
-    } else {
-        // score only: slot k+1 = (D of the previous step's column, V of this step's column) in one 8-byte write a
-        // step -- the D of the step before is still in the register of the other parity (10 % on the 2^16 pair)
-        const int Dprev = (k & 1) ? S.D0 : S.D1;
-        int2* slot = (k + 1 < kBlk) ? (int2*)(pa + 2 * (k + 1)) : (int2*)(pb + 2 * (k + 1 - kBlk));
-        *slot = make_int2(Dprev, S.V);
-    }
+    // publish (committed values).  Slot s of the block = (D of step s-2, V of step s-1); slots k and k+1 leave together
+    // after every even step as ONE 16-byte write.  An LDS instruction keeps the wavefront that issues it from issuing
+    // anything else for 16 (4 bytes a lane), 20 (8) or 30 (16) cycles -- a VALU instruction for 5 -- so one write per two
+    // steps instead of one per step is worth 5 cycles a step to a wavefront that has its SIMD to itself (tools/exp/
+    // lds_issue.hip, step_mix.hip).  Slot 16 (and D of the last step, in slot 17) is written by the next block's first
+    // step, or by run_block after the strip's last block.
+    if ((k & 1) == 0) *(int4*)(pa + 2 * k) = make_int4(Dm2, Vm1, S.D1, S.V);
 }
 
 // LDS counters: the LDS executes one wavefront's instructions in order, so data written before
@@ -298,7 +292,9 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     const bool to_hbm = (OUT == kAny) ? c.to_hbm : (OUT == kOutHbm);
     // ---- 1. lane 0's inputs for columns t0..t0+15: ring slots t0+64..t0+79 ----
     const int slot0 = (t0 + 64) & (kRing - 1);
-    const int4* rp = (const int4*)(c.my_ring + slot0);
+    // (only lane 0 uses what it reads.  The other lanes read the 16 bytes that follow their neighbour's -- whatever lies
+    // there, inside FillLds -- instead of the same 16: sixty-four lanes on one address cost the LDS twice the cycles)
+    const int4* rp = (const int4*)(c.my_ring + slot0) + lane;
     int4 pre[8];
     bool pre_loaded = false;
     if (from_lds) {
@@ -425,10 +421,13 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     if (IN == kAny || IN == kInLds) lds_post(c.cons_post, t0 + 80);
 
     int* pa = c.out_base + (c.out_wrap ? ((2 * t0) & (c.out_wrap - 1)) : 0);
-    int* pb = c.out_base + (c.out_wrap ? ((2 * (t0 + kBlk)) & (c.out_wrap - 1)) : 0);
+
+    // ---- 2. the sixteen steps ----
+    step16<CODES, MODE>(0, c.S, pre[0], mq[0], pa, t0, lane, W, c.row_ok);
 
     // A strip that publishes through HBM reads back what lane 63 dropped into the staging slots
-    // during the PREVIOUS block (columns t0-80 .. t0-65, complete since step t0-2) and stores the
+    // during the PREVIOUS block and in the step just done (columns t0-80 .. t0-65: slots t0-16 .. t0, the
+    // last of which left with step 0's write; the LDS runs a wavefront's instructions in order) and stores the
     // granules a few steps into this block: the LDS round trip hides behind those steps.
     constexpr int kFlushAt = 4;
     constexpr bool flush_always = (MODE == kFast && OUT == kOutHbm);   // no branch, no mask (see the request above)
@@ -436,17 +435,16 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     const int fcol = t0 - 80 + (flush_always ? (lane & (kBlk - 1)) : lane);
     const bool flush = to_hbm && t0 >= 80 && t0 - 80 < W;
     int fv = 0, fd = 0;
+    PSA_COMPILER_BARRIER();
     if (flush_always || (flush && lane < kBlk && fcol < W)) {
         // staging slot of column c is c + 64 (numbered like the ring): V in .y of the slot, D in .x of the next
         fv = lds.stage[c.wv][(fcol + 64) & 31].y;
         fd = lds.stage[c.wv][(fcol + 65) & 31].x;
     }
     PSA_COMPILER_BARRIER();
-
-    // ---- 2. the sixteen steps ----
 #pragma unroll
-    for (int k = 0; k < kFlushAt; ++k) {
-        step16<CODES, MODE>(k, c.S, pre[k >> 1], mq[k >> 2], pa, pb, t0 + k, lane, W, c.row_ok);
+    for (int k = 1; k < kFlushAt; ++k) {
+        step16<CODES, MODE>(k, c.S, pre[k >> 1], mq[k >> 2], pa, t0 + k, lane, W, c.row_ok);
         if (CODES && (k & 3) == 3) c.qd[4 * JB + (k >> 2)] = c.S.acc;
     }
     if (OUT == kAny || OUT == kOutHbm) {
@@ -465,8 +463,13 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     }
 #pragma unroll
     for (int k = kFlushAt; k < kBlk; ++k) {
-        step16<CODES, MODE>(k, c.S, pre[k >> 1], mq[k >> 2], pa, pb, t0 + k, lane, W, c.row_ok);
+        step16<CODES, MODE>(k, c.S, pre[k >> 1], mq[k >> 2], pa, t0 + k, lane, W, c.row_ok);
         if (CODES && (k & 3) == 3) c.qd[4 * JB + (k >> 2)] = c.S.acc;   // four steps fill a word
+    }
+    // the strip's last block: nobody comes to write slot 16 and the last step's D (slot 17)
+    if (t0 + kBlk == c.nblocks * kBlk) {
+        int* pb = c.out_base + (c.out_wrap ? ((2 * (t0 + kBlk)) & (c.out_wrap - 1)) : 0);
+        *(int4*)pb = make_int4(c.S.D0, c.S.V, c.S.D1, 0);
     }
 
     // ---- 3. publish progress ----
@@ -677,8 +680,8 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
     c.my_ring = lds.ring[wv];
     if (lane == 63 && c.to_lds) { c.out_base = (int*)lds.ring[wv + 1]; c.out_wrap = kRing * 2; }
     else if (lane == 63 && c.to_hbm) { c.out_base = (int*)lds.stage[wv]; c.out_wrap = 32 * 2; }
-    // (lane l's dump slots start 8 l bytes into the row: the lanes' 8-byte writes of a step are consecutive)
-    else { c.out_base = lds.dummy[wv] + 2 * lane; c.out_wrap = 0; }
+    // (lane l's dump slots start 16 l bytes into the row: the lanes' 16-byte writes of a step are consecutive)
+    else { c.out_base = lds.dummy[wv] + 4 * lane; c.out_wrap = 0; }
     c.prod_post = (lane == 63 && c.to_lds) ? &lds.prod[wv + 1] : &lds.dummy2[wv][lane];
     c.cons_post = (lane == 0 && c.from_lds) ? &lds.cons[wv] : &lds.dummy2[wv][lane];
     c.tag_in = (u64)sg;
@@ -785,9 +788,6 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         p.prof[4 * s + 3] = ((u64)c.wait_room << 32) | c.wait_in;
     }
     // ---- trailing granule group (columns whose flush block lies beyond the last block) ----
-    // (score only: a step publishes the D of the step before it: the D of the very last step -- column W-1 when W + 63 is a
-    // multiple of 16 -- is still to be dropped into its slot, number of the last step + 2)
-    if (!CODES && c.to_hbm && lane == 63) ((int*)lds.stage[wv])[(2 * (nblocks * kBlk + 1)) & 63] = c.S.D1;
     if (c.to_hbm) {
         for (int cb = nblocks * kBlk - 80; cb < W; cb += kBlk) {
             if (cb < 0) continue;
