@@ -49,7 +49,7 @@ PROFILE_DIR = os.path.join("profiles", "r2")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--steps", type=int, default=192)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=0, help="rows per inter-GPU hand-off (N > 1, stripes); 0 = from the stripe width")

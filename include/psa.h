@@ -194,6 +194,40 @@ int psa_stripe_set_sequences_dev(psa_stripe* s, const uint8_t* a_dev, const uint
 int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev,
                          int32_t* right_dev, void* stream);
 
+/*
+ * The same fill as ONE launch over all rows 1..n whose boundaries arrive and leave in row chunks WHILE it runs --
+ * the per-row hand-off between neighbouring threads of simple.cpp:136-154 (wait for the left neighbour's row)
+ * and :215-235 (publish the own last column), at the granularity of 64-row strips, for stripes that live on
+ * different GPUs.  A launch per chunk (psa_stripe_fill_rows) leaves a wide stripe's chain with only as many
+ * chunks in flight as there are streams; this one keeps the whole chain alive.
+ * left_dev   : DEVICE int32[3][n], plane k row y = T_{k+1}(1+y, c0); NULL when c0 == 0.
+ * left_ready : DEVICE uint32[(n+63)/64], zeroed by the caller before the call; strip g (rows 64g+1..64g+64) starts
+ *              once left_ready[g] and left_ready[g-1] are non-zero.  psa_edge_post fills a chunk of left_dev from a
+ *              packed [3][rows] buffer (what a neighbour sent) and raises its flags.  NULL: left_dev is complete.
+ * right_dev  : DEVICE int32[3][n] receiving column c1, or NULL.
+ * right_done : DEVICE uint32[(n+63)/64], zeroed by the caller; right_done[g] is raised when strip g's rows of
+ *              right_dev are written.  psa_edge_take waits (on its stream, on the device) for a chunk's last strip
+ *              and packs the chunk as [3][rows] for sending.  NULL: read right_dev after the launch.
+ * The fill, the posts and the takes go to three different streams.  A wait that lasts longer than 60 s (a chunk
+ * that never arrives) ends the launch; psa_stripe_final then returns PSA_E_KERNEL.
+ */
+/* A stream (hipStream_t) for the flagged fill.  HIP multiplexes streams onto a few hardware queues (4 by default),
+ * and a kernel does not start before the kernel queued ahead of it on the same hardware queue has ended: a flagged
+ * fill whose stream shares a queue with the stream that delivers its boundary waits for ever.  The runtime keeps
+ * one pool of hardware queues per stream PRIORITY, so the fill goes to a stream of a priority nothing else uses:
+ * priority_class < 0 lowest (what distributed.py uses: communication kernels win), > 0 highest, 0 normal.
+ * reserved_cus > 0: instead, a stream that leaves that many compute units to other streams
+ * (hipExtStreamCreateWithCUMask: a queue of its own too, but a BLOCKING stream -- it synchronises with the null
+ * stream); experimental. */
+int psa_stream_create(void** stream_out, int priority_class, int reserved_cus);
+int psa_stream_destroy(void* stream);
+int psa_stripe_fill_flagged(psa_stripe* s, const int32_t* left_dev, const uint32_t* left_ready,
+                            int32_t* right_dev, uint32_t* right_done, void* stream);
+int psa_edge_post(const int32_t* packed_dev, int64_t r0, int64_t rows, int64_t n, int32_t* left_dev,
+                  uint32_t* left_ready, void* stream);
+int psa_edge_take(psa_stripe* s, const int32_t* right_dev, const uint32_t* right_done, int64_t r0,
+                  int64_t rows, int32_t* packed_dev, void* stream);
+
 /* T1,T2,T3 at (n, c1) after the last chunk (synchronises `stream`).  For the last stripe
  * pick() of these is the score (simple.cpp:246-256). */
 int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]);

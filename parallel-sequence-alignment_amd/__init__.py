@@ -17,6 +17,7 @@ from .binding import (  # noqa: F401
     align,
     align_many,
     device_count,
+    edge_post,
     finish_alignment,
     format_result,
     lib,
@@ -28,6 +29,8 @@ from .binding import (  # noqa: F401
     run,
     score,
     score_batch,
+    stream_create,
+    stream_destroy,
     set_device,
     synth_protein,
 )

@@ -48,6 +48,11 @@ _SIGNATURES = {
     "psa_stripe_destroy": (None, [C.c_void_p]),
     "psa_stripe_set_sequences_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "psa_stripe_fill_rows": (C.c_int, [C.c_void_p, _i64, _i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psa_stripe_fill_flagged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psa_stream_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
+    "psa_stream_destroy": (C.c_int, [C.c_void_p]),
+    "psa_edge_post": (C.c_int, [C.c_void_p, _i64, _i64, _i64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "psa_edge_take": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i64, _i64, C.c_void_p, C.c_void_p]),
     "psa_stripe_final": (C.c_int, [C.c_void_p, C.c_void_p, _i32p]),
     "psa_stripe_traceback": (C.c_int, [C.c_void_p, _i64p, _i64p, C.POINTER(C.c_int), C.c_void_p, C.c_void_p,
                                        _i64, _i64p, C.c_void_p]),
@@ -369,6 +374,23 @@ class Many:
         return lib().psa_many_code_bytes(self._h, slot)
 
 
+def stream_create(priority_class=-1, reserved_cus=0):
+    """hipStream_t (as an int) of a priority class of its own (-1 lowest, 0 normal, +1 highest) -- a hardware queue no
+    normal stream shares -- or, reserved_cus > 0, one that leaves that many CUs to other streams (psa.h)."""
+    h = C.c_void_p()
+    _check(lib().psa_stream_create(C.byref(h), int(priority_class), int(reserved_cus)))
+    return h.value
+
+
+def stream_destroy(stream):
+    _check(lib().psa_stream_destroy(stream))
+
+
+def edge_post(packed_ptr, r0, rows, n, left_ptr, left_ready_ptr, stream=0):
+    """Queue on `stream`: packed int32[3][rows] -> rows r0+1..r0+rows of the left boundary int32[3][n], then their flags."""
+    _check(lib().psa_edge_post(packed_ptr, r0, rows, n, left_ptr, left_ready_ptr, stream))
+
+
 class Stripe:
     """One column stripe of B on the current GPU (a thread's share in simple.cpp:87-259)."""
 
@@ -392,6 +414,15 @@ class Stripe:
     def fill_rows(self, r0, r1, left_ptr=None, right_ptr=None, stream=0):
         """left_ptr / right_ptr: device addresses (int) of int32[3][r1-r0] or None."""
         _check(lib().psa_stripe_fill_rows(self._h, r0, r1, left_ptr, right_ptr, stream))
+
+    def fill_flagged(self, left_ptr=None, left_ready_ptr=None, right_ptr=None, right_done_ptr=None, stream=0):
+        """One launch over all rows; left_ptr / right_ptr: device int32[3][n]; the flag arrays: device uint32[(n+63)//64],
+        zeroed by the caller (psa.h, psa_stripe_fill_flagged)."""
+        _check(lib().psa_stripe_fill_flagged(self._h, left_ptr, left_ready_ptr, right_ptr, right_done_ptr, stream))
+
+    def edge_take(self, right_ptr, right_done_ptr, r0, rows, packed_ptr, stream=0):
+        """Queue on `stream`: wait for rows r0+1..r0+rows of the right boundary, pack them as int32[3][rows]."""
+        _check(lib().psa_edge_take(self._h, right_ptr, right_done_ptr, r0, rows, packed_ptr, stream))
 
     def final(self, stream=0):
         t = (_i32 * 3)()

@@ -820,4 +820,48 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))
     fill_strips_body<CODES>(B);
 }
 
+// ---- boundary chunks of a flagged fill (psa_stripe_fill_flagged: one launch over all rows of a stripe whose left
+// boundary arrives, and whose right boundary leaves, in row chunks while the launch runs) ----
+// packed[k][y] (k < 3, y < rows) -> plane[k * n + r0 + y].  Stored past this CU's cache: the fill reads them with
+// device-scope loads once it has seen the flags, which edge_flags raises in a launch of its own behind this one.
+__global__ void edge_scatter(const int32_t* packed, int64_t r0, int64_t rows, int64_t n, int32_t* plane) {
+    const int64_t total = 3 * rows, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t k = e / rows, y = e - k * rows;
+        __hip_atomic_store(plane + k * n + r0 + y, packed[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ void edge_flags(uint32_t* flags, unsigned count) {
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) __hip_atomic_store(flags + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Waits until the fill has raised the flag of the chunk's last strip (strips end in order), then
+// plane[k * n + r0 + y] -> packed[k][y].  Gives up (leaving packed as it is) when the fill has given up or after 60 s,
+// and says so in the stripe's abort word.
+__global__ void edge_gather(const int32_t* plane, const uint32_t* done, int64_t r0, int64_t rows, int64_t n, int32_t* packed,
+                            unsigned* abort_flag) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        const uint32_t* f = done + (r0 + rows - 1) / 64;
+        const unsigned long long t0 = wall_clock64();
+        int good = 1;
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(127);
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 2 * kSpinTicks) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+        }
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const int64_t total = 3 * rows, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t k = e / rows, y = e - k * rows;
+        packed[e] = __hip_atomic_load(plane + k * n + r0 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace psa

@@ -381,7 +381,10 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
     }
     HIP_TRY(hipEventRecord(s->ev[0], st));
     if (s->use_v2) {
-        if (int rc = launch_fill_v2(&fb, 1, nullptr, groups_of(fb), fb.base.ticket, with_codes, psa::kKeepoutAloneBytes, st)) return rc;
+        // (a flagged fill keeps every CU occupied with strips that wait for their boundary: the smaller keep-out leaves
+        // the kernels that bring it -- collective library, psa_edge_post -- 77 KB of every CU's LDS)
+        const size_t keepout = (o.left_done || o.right_done) ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes;
+        if (int rc = launch_fill_v2(&fb, 1, nullptr, groups_of(fb), fb.base.ticket, with_codes, keepout, st)) return rc;
     } else if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fb.base);
     else hipLaunchKernelGGL(psa::fill_strips_v1<false>, dim3(strips), dim3(64), 0, st, fb.base);
     HIP_TRY(hipGetLastError());
@@ -547,6 +550,81 @@ int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* l
                          void* stream) {
     if (s && s->band_rows) return fail(PSA_E_STATE, "psa_stripe_fill_rows: a banded stripe is driven by psa_align_banded");
     return fill_rows_impl(s, r0, r1, left_dev, right_dev, stream, FillOpts());
+}
+
+// ---- one launch over all rows, boundaries arriving and leaving by flags (the multi-GPU pipeline) ----
+int psa_stripe_fill_flagged(psa_stripe* s, const int32_t* left_dev, const uint32_t* left_ready, int32_t* right_dev,
+                            uint32_t* right_done, void* stream) {
+    if (!s) return fail(PSA_E_ARG, "psa_stripe_fill_flagged: null stripe");
+    if (s->band_rows) return fail(PSA_E_STATE, "psa_stripe_fill_flagged: a banded stripe is driven by psa_align_banded");
+    if (!s->use_v2) return fail(PSA_E_STATE, "psa_stripe_fill_flagged: needs the v2 fill kernel (alphabet of at most 32 symbols)");
+    if ((left_ready && !left_dev) || (right_done && !right_dev))
+        return fail(PSA_E_ARG, "psa_stripe_fill_flagged: flags without their boundary buffer");
+    FillOpts o;
+    o.left_done = left_ready;
+    o.right_done = right_done;
+    return fill_rows_impl(s, 0, s->n, left_dev, right_dev, stream, o);
+}
+
+int psa_stream_create(void** stream_out, int priority_class, int reserved_cus) {
+    if (!stream_out) return fail(PSA_E_ARG, "psa_stream_create: null argument");
+    hipStream_t st = nullptr;
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (reserved_cus > 0 && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess &&
+        pr.multiProcessorCount > reserved_cus) {
+        const int cus = pr.multiProcessorCount;
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+        for (int c = 0; c < cus - reserved_cus; ++c) mask[(size_t)c / 32] |= 1u << (c % 32);
+        if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            st = nullptr;
+        }
+    }
+    if (!st) {
+        int least = 0, greatest = 0;   // (numerically: least = the lowest priority)
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = priority_class < 0 ? least : priority_class > 0 ? greatest : (least + greatest) / 2;
+        HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio));
+    }
+    *stream_out = (void*)st;
+    return PSA_OK;
+}
+
+int psa_stream_destroy(void* stream) {
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return PSA_OK;
+}
+
+int psa_edge_post(const int32_t* packed_dev, int64_t r0, int64_t rows, int64_t n, int32_t* left_dev, uint32_t* left_ready,
+                  void* stream) {
+    if (!packed_dev || !left_dev || !left_ready || rows < 1 || r0 < 0 || (r0 & 63) || r0 + rows > n)
+        return fail(PSA_E_ARG, "psa_edge_post: bad arguments (r0=%lld rows=%lld n=%lld; r0 must be a multiple of 64)",
+                    (long long)r0, (long long)rows, (long long)n);
+    if (r0 + rows < n && (rows & 63)) return fail(PSA_E_ARG, "psa_edge_post: only the last chunk may have a row count off 64");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)std::min<int64_t>((3 * rows + 255) / 256, 1024);
+    hipLaunchKernelGGL(psa::edge_scatter, dim3(blocks), dim3(256), 0, st, packed_dev, r0, rows, n, left_dev);
+    // (a kernel of its own: everything the scatter stored is visible device-wide when this one starts)
+    const unsigned nflags = (unsigned)((rows + 63) / 64);
+    hipLaunchKernelGGL(psa::edge_flags, dim3((nflags + 255) / 256), dim3(256), 0, st, left_ready + r0 / 64, nflags);
+    HIP_TRY(hipGetLastError());
+    return PSA_OK;
+}
+
+int psa_edge_take(psa_stripe* s, const int32_t* right_dev, const uint32_t* right_done, int64_t r0, int64_t rows,
+                  int32_t* packed_dev, void* stream) {
+    if (!s || !right_dev || !right_done || !packed_dev || rows < 1 || r0 < 0 || (r0 & 63) || r0 + rows > s->n)
+        return fail(PSA_E_ARG, "psa_edge_take: bad arguments (r0=%lld rows=%lld n=%lld; r0 must be a multiple of 64)",
+                    (long long)r0, (long long)rows, s ? (long long)s->n : 0LL);
+    DeviceGuard g(s->device);
+    if (g.rc) return g.rc;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)std::min<int64_t>((3 * rows + 255) / 256, 64);
+    hipLaunchKernelGGL(psa::edge_gather, dim3(blocks), dim3(256), 0, st, right_dev, right_done, r0, rows, s->n, packed_dev,
+                       s->ctrl + kAbortWord);
+    HIP_TRY(hipGetLastError());
+    return PSA_OK;
 }
 
 int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]) {

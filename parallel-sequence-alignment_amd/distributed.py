@@ -13,12 +13,13 @@ gloo in the test-suite (tests inject an oracle-backed engine); the default and o
 engine is the HIP stripe object of the C ABI.
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .binding import Result, Stripe, finish_alignment, pick
+from .binding import PsaError, Result, Stripe, finish_alignment, pick
 
 
 class HipStripeEngine:
@@ -32,6 +33,8 @@ class HipStripeEngine:
         # first strip picks up the rows chunk c's last strip publishes (granules in HBM), so the stripe's
         # dependency chain stays alive across chunk boundaries instead of draining at each of them
         self.streams = [torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)]
+        self.fill_stream, self._fill_stream_h = None, None
+        self.take_stream, self._take_stream_h = None, None
 
     def chunk_stream(self, c):
         return torch.cuda.stream(self.streams[c % 2])
@@ -39,9 +42,47 @@ class HipStripeEngine:
     def sync_chunks(self):
         for s in self.streams:
             s.synchronize()
+        if self.fill_stream is not None:
+            self.fill_stream.synchronize()
 
     def new_edge(self, rows):
         return torch.empty(3 * rows, dtype=torch.int32, device=self.dev)
+
+    # ---- one launch over all rows, boundary chunks arriving and leaving by flags (psa_stripe_fill_flagged) ----
+    flagged = True
+
+    def fill_flagged(self, left, left_ready, right, right_done):
+        """Queue the whole stripe's fill on a stream of its own; left/right: int32[3*n] device tensors or None, the
+        flag tensors int32[(n+63)//64], zeroed."""
+        if self.fill_stream is None:
+            # A stream of the lowest priority: the runtime keeps a pool of hardware queues per priority, so the fill
+            # never sits in a hardware queue AHEAD of a kernel it waits for (the posts, the collective library's
+            # receives: all on normal-priority streams), and those kernels win where they compete for a CU.
+            from .binding import stream_create
+            self._fill_stream_h = stream_create(-1, int(os.environ.get("PSA_FILL_RESERVED_CUS", "0")))
+            self.fill_stream = torch.cuda.ExternalStream(self._fill_stream_h, device=self.dev)
+        self.fill_stream.wait_stream(torch.cuda.current_stream())   # (the flag tensors were zeroed on the current one)
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        self.stripe.fill_flagged(ptr(left), ptr(left_ready), ptr(right), ptr(right_done), self.fill_stream.cuda_stream)
+
+    def out_stream(self):
+        """Where the takes (kernels that wait for a chunk of the right boundary) and the sends behind them are queued:
+        the highest priority, again a pool of hardware queues of its own -- a take must not sit ahead of the next
+        chunk's receive and post in a queue they share."""
+        if self.take_stream is None:
+            from .binding import stream_create
+            self._take_stream_h = stream_create(+1)
+            self.take_stream = torch.cuda.ExternalStream(self._take_stream_h, device=self.dev)
+        return self.take_stream
+
+    def edge_post(self, packed, r0, rows, left, left_ready):
+        from .binding import edge_post
+        edge_post(packed.data_ptr(), r0, rows, self.n, left.data_ptr(), left_ready.data_ptr(),
+                  torch.cuda.current_stream().cuda_stream)
+
+    def edge_take(self, right, right_done, r0, rows, packed):
+        self.stripe.edge_take(right.data_ptr(), right_done.data_ptr(), r0, rows, packed.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
 
     def fill_rows(self, r0, r1, left, right):
         stream = torch.cuda.current_stream().cuda_stream
@@ -59,6 +100,15 @@ class HipStripeEngine:
         return i, j, k, ai[:ln], bj[:ln]
 
     def close(self):
+        from .binding import stream_destroy
+        if self._fill_stream_h is not None:
+            self.fill_stream.synchronize()
+            stream_destroy(self._fill_stream_h)
+            self.fill_stream, self._fill_stream_h = None, None
+        if self._take_stream_h is not None:
+            self.take_stream.synchronize()
+            stream_destroy(self._take_stream_h)
+            self.take_stream, self._take_stream_h = None, None
         self.stripe.close()
 
 
@@ -81,9 +131,12 @@ def _send(t, dst):
 
 def _recv(t, src):
     if dist.get_backend() == "gloo" and t.is_cuda:
-        tmp = torch.empty(t.shape, dtype=t.dtype)
+        # (pinned + asynchronous: a copy from pageable memory waits for more than its own stream, and a flagged fill
+        # that is waiting for this very chunk never ends)
+        tmp = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         dist.recv(tmp, src)
-        t.copy_(tmp)
+        t.copy_(tmp, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
     else:
         dist.recv(t, src)
 
@@ -98,12 +151,55 @@ def auto_chunk_rows(width):
     return 256 * groups
 
 
-def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEngine, keep_engine=None):
+def _fill_flagged(eng, n, chunk_rows, prev_owner, next_owner):
+    """The stripe's fill as ONE launch; the left boundary arrives from prev_owner and the right boundary leaves for
+    next_owner in chunks of chunk_rows rows while it runs.  Receives + posts are queued on one stream, takes + sends
+    on another, the fill on a third: a chunk is handed on as soon as its last strip has ended, whatever the fill
+    launch is doing elsewhere."""
+    dev = eng.dev
+    strips = (n + 63) // 64
+    left = left_ready = right = right_done = None
+    if prev_owner is not None:
+        left = torch.empty(3 * n, dtype=torch.int32, device=dev)
+        left_ready = torch.zeros(strips, dtype=torch.int32, device=dev)
+    if next_owner is not None:
+        right = torch.empty(3 * n, dtype=torch.int32, device=dev)
+        right_done = torch.zeros(strips, dtype=torch.int32, device=dev)
+    eng.fill_flagged(left, left_ready, right, right_done)
+    rows_max = min(chunk_rows, n)
+    s_in, s_out = torch.cuda.Stream(device=dev), eng.out_stream()
+    s_in.wait_stream(torch.cuda.current_stream())
+    s_out.wait_stream(torch.cuda.current_stream())
+    inbuf = [torch.empty(3 * rows_max, dtype=torch.int32, device=dev) for _ in range(2)] if left is not None else None
+    outbuf = [torch.empty(3 * rows_max, dtype=torch.int32, device=dev) for _ in range(2)] if right is not None else None
+    for c, r0 in enumerate(range(0, n, chunk_rows)):
+        rows = min(n, r0 + chunk_rows) - r0
+        if left is not None:
+            with torch.cuda.stream(s_in):
+                buf = inbuf[c % 2][:3 * rows]
+                _recv(buf, prev_owner)
+                eng.edge_post(buf, r0, rows, left, left_ready)
+        if right is not None:
+            with torch.cuda.stream(s_out):
+                buf = outbuf[c % 2][:3 * rows]
+                eng.edge_take(right, right_done, r0, rows, buf)
+                _send(buf, next_owner)
+    s_in.synchronize()
+    s_out.synchronize()
+    eng.sync_chunks()
+    for t in (left, left_ready, right, right_done):   # (used on streams other than the one they were made on)
+        if t is not None:
+            t.record_stream(eng.fill_stream)
+
+
+def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEngine, keep_engine=None, flagged=None):
     """Align A against B with B cut into world_size column stripes, one per rank.
 
     Every rank calls this with the same a, b.  Returns Result(score, ai, bj) on every rank
     (ai, bj are empty arrays when traceback is False).  chunk_rows (multiple of 64; None or 0: chosen
     from the stripe width, auto_chunk_rows) is the hand-off granularity between neighbouring ranks.
+    flagged=False: one fill launch per chunk (psa_stripe_fill_rows) instead of one launch over all rows whose
+    boundaries arrive and leave by flags (psa_stripe_fill_flagged, the default where the engine has it).
     """
     world, rank = dist.get_world_size(), dist.get_rank()
     a = np.ascontiguousarray(np.frombuffer(a, np.uint8) if isinstance(a, (bytes, bytearray)) else a, np.uint8)
@@ -129,6 +225,18 @@ def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEng
     eng = None
     if width > 0:
         eng = keep_engine if keep_engine is not None else engine_cls(a, b, c0, c1, traceback)
+        if flagged is None:
+            # ranks that share one GPU (rehearsals) would hold each other's CUs with waiting strips
+            flagged = int(os.environ.get("LOCAL_WORLD_SIZE", world)) <= max(1, torch.cuda.device_count())
+        if getattr(eng, "flagged", False) and flagged:
+            try:
+                _fill_flagged(eng, n, chunk_rows, prev_owner, next_owner)
+                chunk_rows = None
+            except PsaError as e:
+                if e.code != -6:    # PSA_E_STATE before anything was queued: this stripe needs the generic kernel
+                    raise
+    if eng is not None and chunk_rows is not None:
+        # (engines without the flagged fill, or flagged=False: one launch per chunk)
         # two chunks are in flight at a time (alternating streams): two boundary buffers each way
         left = [eng.new_edge(min(chunk_rows, n)) for _ in range(2)] if prev_owner is not None else None
         right = [eng.new_edge(min(chunk_rows, n)) for _ in range(2)] if next_owner is not None else None

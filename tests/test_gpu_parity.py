@@ -494,3 +494,60 @@ def test_chunks_in_flight_on_alternating_streams():
         fa, fb = psa_amd.finish_alignment(xa[:ln], xb[:ln], n, m)
         assert np.array_equal(fa, ai) and np.array_equal(fb, bj), chunk
     s0.close(); s1.close()
+
+
+@pytest.mark.gpu
+def test_flagged_fill_boundaries_by_flags():
+    """psa_stripe_fill_flagged: each stripe is ONE launch over all rows; the right boundary of the head stripe leaves in
+    chunks (psa_edge_take waits on the device for a chunk's last strip) and arrives at the next stripe in chunks
+    (psa_edge_post raises the strips' flags) while both launches run -- the multi-GPU pipeline on one GPU.  The tail
+    stripe is launched FIRST, so every one of its strips starts out waiting."""
+    import torch
+    rng = np.random.default_rng(77)
+    n, m, cut = 6000, 5000, 2100
+    a = rng.integers(65, 69, n).astype(np.uint8)
+    b = np.where(rng.random(m) < 0.7, np.resize(a, m), rng.integers(65, 69, m)).astype(np.uint8)
+    sc, ai, bj = O.align(a, b)
+    s0 = psa_amd.Stripe(a, b, 0, cut, traceback=True)
+    s1 = psa_amd.Stripe(a, b, cut, m, traceback=True)
+    strips = (n + 63) // 64
+    # (each fill on a stream of a priority class of its own, i.e. a hardware queue no other stream here shares: psa.h)
+    f0, f1 = psa_amd.stream_create(+1), psa_amd.stream_create(-1)
+    s_in, s_out = torch.cuda.Stream(), torch.cuda.Stream()
+    for chunk in (1024, 64 * 5, 8192):
+        right = torch.empty(3 * n, dtype=torch.int32, device="cuda")
+        left = torch.full((3 * n,), 0x3f3f3f3f, dtype=torch.int32, device="cuda")
+        right_done = torch.zeros(strips, dtype=torch.int32, device="cuda")
+        left_ready = torch.zeros(strips, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        s1.fill_flagged(left.data_ptr(), left_ready.data_ptr(), None, None, f1)
+        s0.fill_flagged(None, None, right.data_ptr(), right_done.data_ptr(), f0)
+        bufs = []
+        for r0 in range(0, n, chunk):
+            rows = min(n, r0 + chunk) - r0
+            buf = torch.empty(3 * rows, dtype=torch.int32, device="cuda")
+            bufs.append(buf)
+            s0.edge_take(right.data_ptr(), right_done.data_ptr(), r0, rows, buf.data_ptr(), s_out.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(s_out)
+            s_in.wait_event(ev)
+            psa_amd.edge_post(buf.data_ptr(), r0, rows, n, left.data_ptr(), left_ready.data_ptr(), s_in.cuda_stream)
+        torch.cuda.synchronize()
+        assert int(right_done.min()) == 1 and int(left_ready.min()) == 1
+        assert torch.equal(left, right), chunk
+        k, v = psa_amd.pick(*s1.final())
+        assert v == sc, chunk
+        cap = 2 * (n + m) + 2
+        xa, xb = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        i, j, k, ln = s1.traceback(n, m, k, xa, xb, 0)
+        if i > 0 and j > 0:
+            i, j, k, ln = s0.traceback(i, j, k, xa, xb, ln)
+        fa, fb = psa_amd.finish_alignment(xa[:ln], xb[:ln], n, m)
+        assert np.array_equal(fa, ai) and np.array_equal(fb, bj), chunk
+    # flags without their buffer, a chunk off the 64-row grid
+    with pytest.raises(psa_amd.PsaError):
+        s0.fill_flagged(None, None, None, right_done.data_ptr(), f0)
+    with pytest.raises(psa_amd.PsaError):
+        psa_amd.edge_post(bufs[0].data_ptr(), 32, 64, n, left.data_ptr(), left_ready.data_ptr(), 0)
+    s0.close(); s1.close()
+    psa_amd.stream_destroy(f0); psa_amd.stream_destroy(f1)
