@@ -278,7 +278,8 @@ def single_gpu(args):
                    "fill_launches_overlap": bool(args.overlap_fills), "host_threads": 1,
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
-        "roofline": {"bound": "valu", "kernel": "fill_strips_v2_dense<true>: ONE launch filling %d pairs (winner codes on), two wavefronts per SIMD" % per_launch_pairs,
+        "roofline": {"bound": "valu", "kernel": ("fill_strips_v2_dense<true>: ONE launch filling %d pairs (winner codes on), two wavefronts per SIMD" % per_launch_pairs)
+                               if per_launch_pairs > 1 else "fill_strips_v2<true>: one pair per launch (winner codes on), one wavefront per SIMD",
                      "achieved": achieved, "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
                      "ops_per_cell": OPS_PER_CELL_CODES, "cells_per_launch": per_launch_pairs * cells1,
                      "frac_at_survey_ops": achieved / VALU_PEAK_TOPS * SURVEY_OPS_CODES / OPS_PER_CELL_CODES,

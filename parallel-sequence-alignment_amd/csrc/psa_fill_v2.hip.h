@@ -193,8 +193,8 @@ __device__ __forceinline__ void step16(const int k, StripState& S, const int4& p
     // publish (committed values).  Slot s of the block = (D of step s-2, V of step s-1); slots k and k+1 leave together
     // after every even step as ONE 16-byte write.  An LDS instruction keeps the wavefront that issues it from issuing
     // anything else for 16 (4 bytes a lane), 20 (8) or 30 (16) cycles -- a VALU instruction for 5 -- so one write per two
-    // steps instead of one per step is worth 5 cycles a step to a wavefront that has its SIMD to itself (tools/exp/
-    // lds_issue.hip, step_mix.hip).  Slot 16 (and D of the last step, in slot 17) is written by the next block's first
+    // steps instead of one per step is worth 5 cycles a step to a wavefront that has its SIMD to itself
+    // (tools/lds_issue.hip, tools/step_mix.hip).  Slot 16 (and D of the last step, in slot 17) is written by the next block's first
     // step, or by run_block after the strip's last block.
     if ((k & 1) == 0) *(int4*)(pa + 2 * k) = make_int4(Dm2, Vm1, S.D1, S.V);
 }
