@@ -397,11 +397,21 @@ def stripes_figures(args, dist, backend, local):
             b = psa_amd.synth_protein(0xB0000000 + k, m)
             c0, c1 = D.stripe_bounds(m, world, rank)
             eng = D.HipStripeEngine(a, b, c0, c1, traceback=tb)
-            D.align_striped(a, b, chunk_rows=args.chunk_rows, traceback=tb, keep_engine=eng)   # warm-up
+            # One launch per stripe with the boundaries travelling by flags where every rank has its own GPU
+            # (align_striped's default); should that give up on any rank (all ranks raise together), a launch per chunk.
+            flagged = {"0": False, "force": True}.get(os.environ.get("PSA_BENCH_STRIPES_FLAGGED", "1"), None)
+            try:
+                D.align_striped(a, b, chunk_rows=args.chunk_rows, traceback=tb, keep_engine=eng, flagged=flagged)   # warm-up
+            except psa_amd.PsaError as e:
+                if flagged is False:
+                    raise
+                info.setdefault("flagged_fill_gave_up", "%s" % e)
+                flagged = False
+                D.align_striped(a, b, chunk_rows=args.chunk_rows, traceback=tb, keep_engine=eng, flagged=flagged)
             dist.barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
-                res = D.align_striped(a, b, chunk_rows=args.chunk_rows, traceback=tb, keep_engine=eng)
+                res = D.align_striped(a, b, chunk_rows=args.chunk_rows, traceback=tb, keep_engine=eng, flagged=flagged)
             dist.barrier(); torch.cuda.synchronize()
             dtt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64,
                                device="cuda" if backend == "nccl" else "cpu")
@@ -411,6 +421,7 @@ def stripes_figures(args, dist, backend, local):
             ops = OPS_PER_CELL_CODES if tb else OPS_PER_CELL_SCORE
             info["2p%d_%s" % (k, "full_alignment" if tb else "score_only")] = {
                 "ms": sec * 1e3, "gcups": float(n) * m / sec / 1e9, "score": int(res.score), "stripes": world, "scaling": "strong",
+                "fill": "one launch per stripe, boundaries by flags" if (flagged or (flagged is None and int(os.environ.get("LOCAL_WORLD_SIZE", world)) <= torch.cuda.device_count())) else "one launch per row chunk",
                 "valu_frac_of_all_gpus": float(n) * m * ops / sec / 1e12 / (VALU_PEAK_TOPS * world),
                 "structural_ceiling": min(1.0, float(n) * m / ((n + m) * 65536.0 * world))}
     except Exception as e:   # the replica figure must not be lost to the stripes leg

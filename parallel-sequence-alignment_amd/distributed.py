@@ -261,11 +261,25 @@ def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEng
         comm_dev = torch.device("cuda", torch.cuda.current_device())
     else:
         comm_dev = torch.device("cpu")
-    head = torch.zeros(4, dtype=torch.int64, device=comm_dev)  # score, i, j, k
-    if rank == last_owner:
-        t = eng.final()
+    # Every rank looks at its own fill (a wait that expired raises the stripe's abort flag: psa_stripe_final reports
+    # it) and the ranks agree: either all go on or all raise, so that nobody is left alone in a collective.
+    head = torch.zeros(5, dtype=torch.int64, device=comm_dev)  # score, i, j, k, ranks whose fill gave up
+    failed, why, t = 0, "", None
+    if eng is not None:
+        try:
+            t = eng.final()
+        except PsaError as e:
+            failed, why = 1, str(e)
+    if rank == last_owner and not failed:
         kstar, score = pick(*t)
         head[0], head[1], head[2], head[3] = int(score), n, m, kstar
+    head[4] = failed
+    fails = torch.tensor([failed], dtype=torch.int64, device=comm_dev)
+    dist.all_reduce(fails)
+    if int(fails.item()):
+        if eng is not None and keep_engine is None:
+            eng.close()
+        raise PsaError(-5, "align_striped: the fill gave up on %d rank(s)%s" % (int(fails.item()), (" (this one: %s)" % why) if failed else ""))
     dist.broadcast(head, last_owner)
     score = int(head[0].item())
     if not traceback:
