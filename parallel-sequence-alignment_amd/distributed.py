@@ -131,8 +131,8 @@ def _send(t, dst):
 
 def _recv(t, src):
     if dist.get_backend() == "gloo" and t.is_cuda:
-        # (pinned + asynchronous: a copy from pageable memory waits for more than its own stream, and a flagged fill
-        # that is waiting for this very chunk never ends)
+        # (pinned + asynchronous: the copy stays on the current stream and waits for nothing else -- a flagged fill
+        # may be on the GPU waiting for this very chunk)
         tmp = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         dist.recv(tmp, src)
         t.copy_(tmp, non_blocking=True)
@@ -149,6 +149,25 @@ def auto_chunk_rows(width):
     waits for strips of chunk c, which must be able to get a CU)."""
     groups = max(16, min(96, (width // 450 + 1) // 2 + 1))
     return 256 * groups
+
+
+_warmed_up = set()
+
+
+def _warm_up(prev_owner, next_owner):
+    """The first message between two ranks sets the connection up (RCCL allocates and may synchronise the device):
+    get that over with before a launch is on the GPU that waits for those messages.  Every rank that owns a stripe
+    does this, whichever way it fills; gloo needs none."""
+    key = (prev_owner, next_owner)
+    if dist.get_backend() != "nccl" or key in _warmed_up:
+        return
+    tiny = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    if prev_owner is not None:
+        dist.recv(tiny, prev_owner)
+    if next_owner is not None:
+        dist.send(tiny, next_owner)
+    torch.cuda.synchronize()
+    _warmed_up.add(key)
 
 
 def _fill_flagged(eng, n, chunk_rows, prev_owner, next_owner):
@@ -225,6 +244,7 @@ def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEng
     eng = None
     if width > 0:
         eng = keep_engine if keep_engine is not None else engine_cls(a, b, c0, c1, traceback)
+        _warm_up(prev_owner, next_owner)
         if flagged is None:
             # ranks that share one GPU (rehearsals) would hold each other's CUs with waiting strips
             flagged = int(os.environ.get("LOCAL_WORLD_SIZE", world)) <= max(1, torch.cuda.device_count())
