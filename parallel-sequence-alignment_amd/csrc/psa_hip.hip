@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1041,7 +1042,16 @@ int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uin
             return fail(e_ == hipErrorOutOfMemory ? PSA_E_NOMEM : PSA_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
         }                                                                                                      \
     } while (0)
-    MANY_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    {
+        // Engines alternate between two stream priorities: the runtime keeps a pool of hardware queues per priority,
+        // so two engines that take turns never share a hardware queue (kernels of one queue run in order: the
+        // fill of one engine would wait for the other's walks and copies instead of running beside them).
+        static std::atomic<unsigned> engines_made{0};
+        int least = 0, greatest = 0;
+        MANY_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const int prio = (engines_made++ & 1u) ? greatest : (least + greatest) / 2;
+        MANY_TRY(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio));
+    }
     for (auto& x : e->ev) MANY_TRY(hipEventCreate(&x));
     MANY_TRY(hipMalloc(&e->ticket, 256));
     MANY_TRY(hipHostMalloc(&e->h_state, sizeof(int64_t) * 16 * slots));
