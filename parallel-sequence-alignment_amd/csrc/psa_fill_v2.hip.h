@@ -282,7 +282,7 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 enum : int { kAny = -1, kInLds = 0, kInHbm = 1, kInTop = 2, kOutLds = 0, kOutHbm = 1, kOutNone = 2 };
 
 // One block of 16 steps: wait for lane 0's inputs, load them, run the steps, post progress.
-template <bool CODES, int MODE, int IN, int OUT, int JB>
+template <bool CODES, bool DENSE, int MODE, int IN, int OUT, int JB>
 __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, const int t0,
                                           const unsigned (&mq)[4]) {
     const int lane = c.lane;
@@ -418,7 +418,10 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) pre[j] = rp[j];
     }
-    if (IN == kAny || IN == kInLds) lds_post(c.cons_post, t0 + 80);
+    // One pair alone: once per superblock is enough -- the strip above looks once per superblock, a superblock ahead
+    // of its need, and this strip trails by 80 of the ring's 256 slots; a post is an LDS instruction, 16 issue cycles
+    // (7.03 -> 6.95 ms).  Independent pairs sharing the SIMDs: every block (the sparser post cost that launch 5 %).
+    if ((IN == kAny || IN == kInLds) && (DENSE || JB == 3)) lds_post(c.cons_post, t0 + 80);
 
     int* pa = c.out_base + (c.out_wrap ? ((2 * t0) & (c.out_wrap - 1)) : 0);
 
@@ -481,7 +484,7 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
 // here, once per 64 steps, so that no wait on the vector-memory counter sits in the 16-step
 // path: the substitution-table words of the NEXT superblock are requested at the start of
 // this one, the winner bits of this one are stored at its end.
-template <bool CODES, int MODE, int IN, int OUT>
+template <bool CODES, bool DENSE, int MODE, int IN, int OUT>
 __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, const int sb) {
     const int t0 = sb * 64;
     // table words one superblock ahead (16 new words; word 16 of the current set is word 0 of the next)
@@ -514,7 +517,7 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
                                 __builtin_amdgcn_alignbit(c.mw[4 * j + 2], c.mw[4 * j + 1], c.msh),    \
                                 __builtin_amdgcn_alignbit(c.mw[4 * j + 3], c.mw[4 * j + 2], c.msh),    \
                                 __builtin_amdgcn_alignbit(c.mw[4 * j + 4], c.mw[4 * j + 3], c.msh)};   \
-        if (!run_block<CODES, MODE, IN, OUT, j>(c, lds, p, t0 + j * kBlk, mq)) return false;           \
+        if (!run_block<CODES, DENSE, MODE, IN, OUT, j>(c, lds, p, t0 + j * kBlk, mq)) return false;           \
     }
     PSA_BLOCK(0)
     PSA_BLOCK(1)
@@ -537,26 +540,26 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
     return true;
 }
 
-template <bool CODES, int IN, int OUT>
+template <bool CODES, bool DENSE, int IN, int OUT>
 __device__ __forceinline__ bool run_steady(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
     // superblock 0 is the head (lanes entering), then the unpredicated steady state
     if (lo == 0 && hi > 0) {
-        if (!run_superblock<CODES, kHead, IN, OUT>(c, lds, p, 0)) return false;
+        if (!run_superblock<CODES, DENSE, kHead, IN, OUT>(c, lds, p, 0)) return false;
         lo = 1;
     }
     if (IN == kInHbm && kGranCols > kBlk)   // first batch of the steady state
         c.gbatch = load_granule(c.gin + min(64 * lo + (c.lane & (kGranCols - 1)), c.W - 1));
     for (int sb = lo; sb < hi; ++sb)
-        if (!run_superblock<CODES, kFast, IN, OUT>(c, lds, p, sb)) return false;
+        if (!run_superblock<CODES, DENSE, kFast, IN, OUT>(c, lds, p, sb)) return false;
     if (IN == kInHbm && kGranCols > kBlk) c.gq_valid = 0;   // the tail fetches for itself
     return true;
 }
 
-template <bool CODES, int IN>
+template <bool CODES, bool DENSE, int IN>
 __device__ __forceinline__ bool run_steady_out(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
-    if (c.to_lds) return run_steady<CODES, IN, kOutLds>(c, lds, p, lo, hi);
-    if (c.to_hbm) return run_steady<CODES, IN, kOutHbm>(c, lds, p, lo, hi);
-    return run_steady<CODES, IN, kOutNone>(c, lds, p, lo, hi);
+    if (c.to_lds) return run_steady<CODES, DENSE, IN, kOutLds>(c, lds, p, lo, hi);
+    if (c.to_hbm) return run_steady<CODES, DENSE, IN, kOutHbm>(c, lds, p, lo, hi);
+    return run_steady<CODES, DENSE, IN, kOutNone>(c, lds, p, lo, hi);
 }
 
 // The capturing tail (lanes leave on the right and keep their values at column W-1), compiled per role for
@@ -564,22 +567,22 @@ __device__ __forceinline__ bool run_steady_out(StripCtx<CODES>& c, FillLds& lds,
 // between their ends is that number times the duration of a step in the section they end in: a tail that
 // decides its role at run time (2-3 x the instructions per block) cost stripes with a right boundary a third
 // of the whole fill.
-template <bool CODES, int IN, int OUT>
+template <bool CODES, bool DENSE, int IN, int OUT>
 __device__ __forceinline__ bool run_tail(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
     for (int sb = lo; sb < hi; ++sb)
-        if (!run_superblock<CODES, kTail, IN, OUT>(c, lds, p, sb)) return false;
+        if (!run_superblock<CODES, DENSE, kTail, IN, OUT>(c, lds, p, sb)) return false;
     return true;
 }
-template <bool CODES>
+template <bool CODES, bool DENSE>
 __device__ __forceinline__ bool run_tail_roles(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
-    if (c.from_lds && c.to_lds) return run_tail<CODES, kInLds, kOutLds>(c, lds, p, lo, hi);
-    if (c.from_lds && c.to_hbm) return run_tail<CODES, kInLds, kOutHbm>(c, lds, p, lo, hi);
-    if (!c.from_lds && !c.top_analytic && c.to_lds) return run_tail<CODES, kInHbm, kOutLds>(c, lds, p, lo, hi);
-    return run_tail<CODES, kAny, kAny>(c, lds, p, lo, hi);
+    if (c.from_lds && c.to_lds) return run_tail<CODES, DENSE, kInLds, kOutLds>(c, lds, p, lo, hi);
+    if (c.from_lds && c.to_hbm) return run_tail<CODES, DENSE, kInLds, kOutHbm>(c, lds, p, lo, hi);
+    if (!c.from_lds && !c.top_analytic && c.to_lds) return run_tail<CODES, DENSE, kInHbm, kOutLds>(c, lds, p, lo, hi);
+    return run_tail<CODES, DENSE, kAny, kAny>(c, lds, p, lo, hi);
 }
 
 // The body of the fill kernels (two entry points below differ in their occupancy attribute only).
-template <bool CODES>
+template <bool CODES, bool DENSE>
 __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
     __shared__ FillLds lds;
     __shared__ unsigned wg_ticket;
@@ -747,14 +750,14 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         const bool capture = p.right != nullptr || (row_base < p.n && p.n <= row_base + 64);
         const int fast_hi = capture ? (W - 1) / 64 : p.Q;
         bool ok;
-        if (c.from_lds) ok = run_steady_out<CODES, kInLds>(c, lds, p, 0, fast_hi);
-        else if (c.top_analytic) ok = run_steady_out<CODES, kInTop>(c, lds, p, 0, fast_hi);
-        else ok = run_steady_out<CODES, kInHbm>(c, lds, p, 0, fast_hi);
+        if (c.from_lds) ok = run_steady_out<CODES, DENSE, kInLds>(c, lds, p, 0, fast_hi);
+        else if (c.top_analytic) ok = run_steady_out<CODES, DENSE, kInTop>(c, lds, p, 0, fast_hi);
+        else ok = run_steady_out<CODES, DENSE, kInHbm>(c, lds, p, 0, fast_hi);
         if (!ok) return;
-        if (!run_tail_roles<CODES>(c, lds, p, fast_hi, p.Q)) return;
+        if (!run_tail_roles<CODES, DENSE>(c, lds, p, fast_hi, p.Q)) return;
     } else {
         for (int sb = 0; sb < p.Q; ++sb)
-            if (!run_superblock<CODES, kGeneric, kAny, kAny>(c, lds, p, sb)) return;
+            if (!run_superblock<CODES, DENSE, kGeneric, kAny, kAny>(c, lds, p, sb)) return;
     }
     // right boundary / final triple, captured when each lane passed column W-1
     if (row_ok) {
@@ -808,7 +811,7 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
 // dynamic-LDS keep-out keeps a second workgroup off the CU.
 template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void fill_strips_v2(FillBatch B) {
-    fill_strips_body<CODES>(B);
+    fill_strips_body<CODES, false>(B);
 }
 // Independent pairs in one launch: the chains of different pairs do not wait for each other, and a lone
 // wavefront uses less than half of its SIMD's issue slots (one instruction per 4.7 cycles, 12.5 of 21 of them
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))
 // a lone pair, which is why the sparse kernel stays).
 template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fill_strips_v2_dense(FillBatch B) {
-    fill_strips_body<CODES>(B);
+    fill_strips_body<CODES, true>(B);
 }
 
 // ---- boundary chunks of a flagged fill (psa_stripe_fill_flagged: one launch over all rows of a stripe whose left
