@@ -26,6 +26,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -232,14 +233,6 @@ def single_gpu(args):
     for e in engines:
         e.close()
 
-    stripes_info = None
-    if dist and not args.no_stripes:
-        stripes_info = stripes_figures(args, dist, backend, local)
-    if rank != 0:
-        dist.barrier()                    # rank 0 is still measuring; leave together
-        dist.destroy_process_group()
-        return None
-
     # ---- the dominant kernel: the fill launch over S pairs, HIP events on the engine's stream, timed region ----
     full = [f for f, cnt in fills if cnt == S] or [f for f, cnt in fills]
     per_launch_pairs = S if any(cnt == S for _, cnt in fills) else fills[0][1]
@@ -249,21 +242,6 @@ def single_gpu(args):
     grid = per_launch_pairs * ((n + 255) // 256)
     traffic, traffic_src = pmc_traffic("<true>(psa::FillBatch)", grid * 256)
 
-    # ---- the same alignment alone on the GPU: latency of one pair, and the one-pair fill kernel ----
-    one = psa_amd.Many(1, n, m, traceback=True)
-    lat, f1, w1 = [], [], []
-    for rep in range(4):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        one.set_pair_dev(0, a_dev.data_ptr(), n, b_dev.data_ptr(), m)
-        one.launch()
-        r = one.result(0, n, m)
-        lat.append((time.perf_counter() - t1) * 1e3)
-        assert (r.score, len(r.ai)) == (sc, ln)
-        f, w = one.last_ms()
-        f1.append(f); w1.append(w)
-    one.close()
-    lat_ms, fill1, walk1 = min(lat[1:]), sum(f1[1:]) / 3, sum(w1[1:]) / 3
     out = {
         "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of 2^%d x 2^%d pairs" % (k, k),
         "value": cells / (dt / args.steps) / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
@@ -291,17 +269,58 @@ def single_gpu(args):
                                        "region; the other engine's walks (one wavefront per pair) run beside it",
                      "fill_gcups": per_launch_pairs * cells1 / (fill_ms * 1e-3) / 1e9,
                      "aggregate_achieved": aggregate, "aggregate_frac": aggregate / VALU_PEAK_TOPS,
-                     "one_pair_alone": {"kernel_ms": fill1, "frac": cells1 * OPS_PER_CELL_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                                        "frac_at_survey_ops": cells1 * SURVEY_OPS_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
-                                        "structural_ceiling": min(1.0, cells1 / ((n + m) * 65536.0))},
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (separate --pmc passes)",
                      "traffic_source": traffic_src,
                      "code_stream": {"bytes_per_launch": code_bytes * per_launch_pairs,
                                      "GBps": code_bytes * per_launch_pairs / (fill_ms * 1e-3) / 1e9,
                                      "frac_of_hbm_peak": code_bytes * per_launch_pairs / (fill_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
-        "one_pair_alone": {"ms": lat_ms, "gcups": cells1 / (lat_ms * 1e-3) / 1e9, "fill_ms": fill1, "traceback_ms": walk1},
         "traceback_ms": sum(walks) / len(walks),
     }
+    stripes_info = None
+    if dist and not args.no_stripes:
+        # The stripes leg is the first place a run meets RCCL under a resident fill: it runs under a deadline, and a
+        # leg that overruns it costs its own figures only (rank 0 prints the line measured above, all ranks leave).
+        deadline = float(os.environ.get("PSA_BENCH_STRIPES_DEADLINE_S", "150"))
+
+        def overrun():
+            if rank == 0:
+                out["stripes"] = {"error": "stripes leg not finished after %.0f s: abandoned, replica figures above stand" % deadline}
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(deadline + (5.0 if rank == 0 else 0.0), overrun)   # (rank 0 last: its line is the one that counts)
+        watchdog.daemon = True
+        watchdog.start()
+        stripes_info = stripes_figures(args, dist, backend, local)
+        watchdog.cancel()
+    if rank != 0:
+        try:
+            dist.barrier()                # rank 0 is still measuring; leave together
+            dist.destroy_process_group()
+        except Exception as e:            # (a peer that left at the deadline above: this rank has nothing to print)
+            print("bench: rank %d leaves without the closing barrier (%s)" % (rank, e), file=sys.stderr)
+        return None
+
+    # ---- the same alignment alone on the GPU: latency of one pair, and the one-pair fill kernel ----
+    one = psa_amd.Many(1, n, m, traceback=True)
+    lat, f1, w1 = [], [], []
+    for rep in range(4):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        one.set_pair_dev(0, a_dev.data_ptr(), n, b_dev.data_ptr(), m)
+        one.launch()
+        r = one.result(0, n, m)
+        lat.append((time.perf_counter() - t1) * 1e3)
+        assert (r.score, len(r.ai)) == (sc, ln)
+        f, w = one.last_ms()
+        f1.append(f); w1.append(w)
+    one.close()
+    lat_ms, fill1, walk1 = min(lat[1:]), sum(f1[1:]) / 3, sum(w1[1:]) / 3
+    out["roofline"]["one_pair_alone"] = {"kernel_ms": fill1, "frac": cells1 * OPS_PER_CELL_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                         "frac_at_survey_ops": cells1 * SURVEY_OPS_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                         "structural_ceiling": min(1.0, cells1 / ((n + m) * 65536.0))}
+    out["one_pair_alone"] = {"ms": lat_ms, "gcups": cells1 / (lat_ms * 1e-3) / 1e9, "fill_ms": fill1, "traceback_ms": walk1}
     if stripes_info is not None:
         out["stripes"] = stripes_info
     extra = {}
@@ -336,8 +355,11 @@ def single_gpu(args):
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a, b)
     if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:            # (peers that left at the stripes deadline: the line is measured, print it)
+            print("bench: closing barrier failed (%s)" % e, file=sys.stderr)
     return out
 
 
@@ -439,6 +461,9 @@ def main():
         out = single_gpu(args)              # independent alignments on every GPU (weak scaling)
     if out is not None:
         print(json.dumps(out))
+        sys.stdout.flush()
+        if world > 1 and isinstance(out.get("stripes"), dict) and "error" in out["stripes"]:
+            os._exit(0)                     # (a process group whose stripes leg failed may not shut down: the line is out)
 
 
 if __name__ == "__main__":
