@@ -819,11 +819,35 @@ int run_stripes(StripeSet& set, int32_t triple[3]) {
             order_dev = set.order;
         }
         psa_stripe* s0 = set.st[g0];
+        // diagnostic only (PSA_PROFILE_STRIPES=path): per-strip start/end ticks of every stripe of the launch
+        const char* prof_path = getenv("PSA_PROFILE_STRIPES");
+        const size_t strips = (size_t)((n + 63) / 64);
+        psa::u64* prof_dev = nullptr;
+        if (prof_path) {
+            HIP_TRY(hipMalloc(&prof_dev, sizeof(psa::u64) * 4 * strips * nj));
+            HIP_TRY(hipMemset(prof_dev, 0, sizeof(psa::u64) * 4 * strips * nj));
+            for (int j = 0; j < nj; ++j) jobs[j].base.prof = prof_dev + 4 * strips * j;
+        }
         HIP_TRY(hipEventRecord(s0->ev[0], nullptr));
         if (int rc = launch_fill_v2(jobs, nj, order_dev, total, jobs[0].base.ticket, with_codes,
                                     nj > 1 ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes, nullptr)) return rc;
         HIP_TRY(hipEventRecord(s0->ev[1], nullptr));
         s0->fill_timed = true;
+        if (prof_dev) {
+            std::vector<psa::u64> h(4 * strips * nj);
+            HIP_TRY(hipMemcpy(h.data(), prof_dev, sizeof(psa::u64) * h.size(), hipMemcpyDeviceToHost));
+            if (FILE* f = fopen(prof_path, "w")) {
+                fprintf(f, "stripe,strip,start,end,xcc,hwid,wait_in,wait_room\n");
+                for (int j = 0; j < nj; ++j)
+                    for (size_t k = 0; k < strips; ++k) {
+                        const psa::u64* q = &h[4 * (strips * j + k)];
+                        fprintf(f, "%d,%zu,%lld,%lld,%llu,%llu,%llu,%llu\n", j, k, (long long)(q[0] - h[0]), (long long)(q[1] - h[0]),
+                                q[2] >> 32, q[2] & 0xffffffffu, q[3] & 0xffffffffu, q[3] >> 32);
+                    }
+                fclose(f);
+            }
+            hipFree(prof_dev);
+        }
     }
     for (size_t g = 0; g + 1 < ns; ++g)   // (an expired wait anywhere fails the call, not only in the last stripe)
         if (int rc = check_abort(set.st[g], nullptr)) return rc;
