@@ -123,6 +123,7 @@ struct __attribute__((aligned(128))) FillLds {
     int dummy2[kNW][64];         // where lanes that own no counter drop their counter posts
     int prod[kNW];               // steps completed by the producer of ring[w]
     int cons[kNW];               // ring[w] slots below this number have been read
+    int snap[kNW][6][64];        // a strip's state at the superblock that holds column W-1 (run_capture_pass)
 };
 
 // Winner code of one cell (layout: psa_device.hip.h, "winner codes"): the byte (11*D + 4*H' + V') & 0xff
@@ -271,6 +272,7 @@ struct StripCtx {
     unsigned gq_valid;      // (u) bit j: gq[j] holds a request
     unsigned qd[16];        // winner codes of the current superblock (see run_superblock)
     unsigned wait_in, wait_room;  // (u) spin iterations, for the profile only
+    int snap_sb;            // (u) REPLAY kernels: the superblock at whose start the state is kept (-1: none)
 };
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -279,7 +281,9 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 // compiled once per role so that a role's code holds only its own memory operations (a wait on
 // the vector-memory counter placed for one role's loads would stall every other role too);
 // kAny = decided at run time from the context flags (head and tail of a strip).
-enum : int { kAny = -1, kInLds = 0, kInHbm = 1, kInTop = 2, kOutLds = 0, kOutHbm = 1, kOutNone = 2 };
+// kInReplay = the strip's second pass over its last superblocks (see fill_strips_body): lane 0's inputs are in the ring
+// already, nothing is waited for, fetched or posted.
+enum : int { kAny = -1, kInLds = 0, kInHbm = 1, kInTop = 2, kInReplay = 3, kOutLds = 0, kOutHbm = 1, kOutNone = 2 };
 
 // One block of 16 steps: wait for lane 0's inputs, load them, run the steps, post progress.
 template <bool CODES, bool DENSE, int MODE, int IN, int OUT, int JB>
@@ -297,7 +301,9 @@ __device__ __forceinline__ bool run_block(StripCtx<CODES>& c, FillLds& lds, cons
     const int4* rp = (const int4*)(c.my_ring + slot0) + lane;
     int4 pre[8];
     bool pre_loaded = false;
-    if (from_lds) {
+    if (IN == kInReplay) {
+        // (the ring holds this block's slots since the first pass)
+    } else if (from_lds) {
         if (MODE == kFast || MODE == kHead || t0 < W) {   // (no run-time condition in the steady state)
             // slots t0+64..t0+79 are complete once the producer has finished step t0+78; it stops at nblocks*16
             const int need = min(t0 + 80, c.nblocks * kBlk);
@@ -540,7 +546,7 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
     return true;
 }
 
-template <bool CODES, bool DENSE, int IN, int OUT>
+template <bool CODES, bool DENSE, bool SNAP, int IN, int OUT>
 __device__ __forceinline__ bool run_steady(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
     // superblock 0 is the head (lanes entering), then the unpredicated steady state
     if (lo == 0 && hi > 0) {
@@ -549,24 +555,48 @@ __device__ __forceinline__ bool run_steady(StripCtx<CODES>& c, FillLds& lds, con
     }
     if (IN == kInHbm && kGranCols > kBlk)   // first batch of the steady state
         c.gbatch = load_granule(c.gin + min(64 * lo + (c.lane & (kGranCols - 1)), c.W - 1));
-    for (int sb = lo; sb < hi; ++sb)
+    for (int sb = lo; sb < hi; ++sb) {
+        if (SNAP && sb == c.snap_sb) {   // (kept in LDS, not in registers held across the loop)
+            int (*sn)[64] = lds.snap[c.wv];
+            sn[0][c.lane] = c.S.D0; sn[1][c.lane] = c.S.D1; sn[2][c.lane] = c.S.H; sn[3][c.lane] = c.S.V;
+            sn[4][c.lane] = (int)c.S.acc; sn[5][c.lane] = c.mword_idx;
+        }
         if (!run_superblock<CODES, DENSE, kFast, IN, OUT>(c, lds, p, sb)) return false;
+    }
     if (IN == kInHbm && kGranCols > kBlk) c.gq_valid = 0;   // the tail fetches for itself
     return true;
 }
 
-template <bool CODES, bool DENSE, int IN>
+template <bool CODES, bool DENSE, bool SNAP, int IN>
 __device__ __forceinline__ bool run_steady_out(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
-    if (c.to_lds) return run_steady<CODES, DENSE, IN, kOutLds>(c, lds, p, lo, hi);
-    if (c.to_hbm) return run_steady<CODES, DENSE, IN, kOutHbm>(c, lds, p, lo, hi);
-    return run_steady<CODES, DENSE, IN, kOutNone>(c, lds, p, lo, hi);
+    if (c.to_lds) return run_steady<CODES, DENSE, SNAP, IN, kOutLds>(c, lds, p, lo, hi);
+    if (c.to_hbm) return run_steady<CODES, DENSE, SNAP, IN, kOutHbm>(c, lds, p, lo, hi);
+    return run_steady<CODES, DENSE, SNAP, IN, kOutNone>(c, lds, p, lo, hi);
 }
 
-// The capturing tail (lanes leave on the right and keep their values at column W-1), compiled per role for
-// the roles nearly every strip has.  A strip trails the one above by a fixed number of STEPS, so the time
-// between their ends is that number times the duration of a step in the section they end in: a tail that
-// decides its role at run time (2-3 x the instructions per block) cost stripes with a right boundary a third
-// of the whole fill.
+// The capturing pass.  Lanes leave the stripe on the right one per step, and a strip that owes somebody its values at
+// column W-1 (a right boundary; the last row's final triple) has to keep them as each lane passes: a compare and three
+// selects on top of a step's 8 instructions.  A strip ends a fixed number of STEPS after the strip above (85 inside a
+// workgroup, 142 across two), so done in line those steps cost every strip of such a stripe 1.7 us, 1 023 times over
+// (a lone 16 384-column stripe: 4.11 ms without a right boundary, 5.81 ms with one; profiles/r2/strip_lags_by_boundary_role.txt).
+// So the strip runs to its end in the steady-state code like any other, hands its bottom row on, and THEN goes over
+// its last one or two superblocks a second time from the state it kept (five registers and the table index, in LDS): inputs
+// still in the ring, nothing waited for, nothing handed on (lane 63 rewrites the slots it wrote with the same values),
+// capturing.  The second pass is off the chain: it costs the strip's own wavefront 7 us, on a GPU with CUs to spare.
+template <bool CODES, bool DENSE>
+__device__ __forceinline__ bool run_capture_pass(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
+    int (*sn)[64] = lds.snap[c.wv];
+    c.S.D0 = sn[0][c.lane]; c.S.D1 = sn[1][c.lane]; c.S.H = sn[2][c.lane]; c.S.V = sn[3][c.lane];
+    c.S.acc = (unsigned)sn[4][c.lane]; c.mword_idx = sn[5][c.lane];
+#pragma unroll
+    for (int j = 0; j < 17; ++j) c.mw[j] = c.trow[c.mword_idx + j];
+    for (int sb = lo; sb < hi; ++sb)
+        if (!run_superblock<CODES, DENSE, kTail, kInReplay, kOutNone>(c, lds, p, sb)) return false;
+    return true;
+}
+
+// The capturing tail in line (kernels without the second pass: one pair per launch, independent pairs -- only the strip
+// with the last row captures there), compiled per role for the roles nearly every strip has.
 template <bool CODES, bool DENSE, int IN, int OUT>
 __device__ __forceinline__ bool run_tail(StripCtx<CODES>& c, FillLds& lds, const FillArgs& p, int lo, int hi) {
     for (int sb = lo; sb < hi; ++sb)
@@ -581,8 +611,8 @@ __device__ __forceinline__ bool run_tail_roles(StripCtx<CODES>& c, FillLds& lds,
     return run_tail<CODES, DENSE, kAny, kAny>(c, lds, p, lo, hi);
 }
 
-// The body of the fill kernels (two entry points below differ in their occupancy attribute only).
-template <bool CODES, bool DENSE>
+// The body of the fill kernels (the entry points below differ in their occupancy attribute and in REPLAY).
+template <bool CODES, bool DENSE, bool REPLAY>
 __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
     __shared__ FillLds lds;
     __shared__ unsigned wg_ticket;
@@ -739,27 +769,56 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         p.prof[4 * s + 2] = ((u64)xcc << 32) | hwid;
     }
 
-    // Wide stripes: head + steady state compiled per role, then a tail that captures the right
-    // boundary.  Narrow stripes (W < 128): one generic, fully predicated loop.
+    // Wide stripes: head + steady state compiled per role over ALL superblocks (in the last ones the lanes leave
+    // on the right: nothing they compute there is read again, so no predication).  Strips that owe their values at
+    // column W-1 -- a right boundary was asked for, or this strip holds the last row -- keep the state at the
+    // superblock that holds column W-1 and come back for it below (run_capture_pass).
+    // Narrow stripes (W < 128): one generic, fully predicated loop that captures as it goes.
+    const bool capture = W >= 128 && (p.right != nullptr || (row_base < p.n && p.n <= row_base + 64));
+    const int capture_lo = (W - 1) / 64;
+    c.snap_sb = (REPLAY && capture) ? capture_lo : -1;
     if (W >= 128) {
-        // Superblock sb is steady iff 64 sb + 64 <= W - 1.  The superblocks after that, in which the
-        // lanes leave on the right, need the slower capturing steps only where somebody wants the
-        // values at column W-1: a right boundary was asked for, or this strip holds the last row.
-        // Everywhere else they run in the steady-state code too -- the time a strip needs for its
-        // last ~100 steps is what separates its end from the end of the strip above, 1023 times over.
-        const bool capture = p.right != nullptr || (row_base < p.n && p.n <= row_base + 64);
-        const int fast_hi = capture ? (W - 1) / 64 : p.Q;
+        // REPLAY: every strip goes to its end in the steady-state code.  Else: capturing strips (here: the one with the
+        // last row, and any strip of a stripe with a right boundary that came to this kernel) leave it at the
+        // superblock that holds column W-1 and capture in line.
+        const int fast_hi = (capture && !REPLAY) ? capture_lo : p.Q;
         bool ok;
-        if (c.from_lds) ok = run_steady_out<CODES, DENSE, kInLds>(c, lds, p, 0, fast_hi);
-        else if (c.top_analytic) ok = run_steady_out<CODES, DENSE, kInTop>(c, lds, p, 0, fast_hi);
-        else ok = run_steady_out<CODES, DENSE, kInHbm>(c, lds, p, 0, fast_hi);
+        if (c.from_lds) ok = run_steady_out<CODES, DENSE, REPLAY, kInLds>(c, lds, p, 0, fast_hi);
+        else if (c.top_analytic) ok = run_steady_out<CODES, DENSE, REPLAY, kInTop>(c, lds, p, 0, fast_hi);
+        else ok = run_steady_out<CODES, DENSE, REPLAY, kInHbm>(c, lds, p, 0, fast_hi);
         if (!ok) return;
-        if (!run_tail_roles<CODES, DENSE>(c, lds, p, fast_hi, p.Q)) return;
+        if (!REPLAY && !run_tail_roles<CODES, DENSE>(c, lds, p, fast_hi, p.Q)) return;
     } else {
         for (int sb = 0; sb < p.Q; ++sb)
             if (!run_superblock<CODES, DENSE, kGeneric, kAny, kAny>(c, lds, p, sb)) return;
     }
-    // right boundary / final triple, captured when each lane passed column W-1
+#ifdef PSA_FILL_STATS
+    if (lane == 0) {
+        const unsigned long long st_end = wall_clock64();
+        unsigned long long* stats = (unsigned long long*)(p.ticket + 48);
+        if (wv == 0) { atomicAdd(stats + 0, st_start - st_entry); atomicAdd(stats + 1, st_end - st_start); }
+        if (wv == kNW - 1 || s == strips - 1) atomicAdd(stats + 2, st_end - st_entry);
+    }
+#endif
+    if (p.prof && lane == 0) {   // (the end of what the strips below wait for)
+        p.prof[4 * s + 1] = wall_clock64();
+        p.prof[4 * s + 3] = ((u64)c.wait_room << 32) | c.wait_in;
+    }
+    // ---- trailing granule group (columns whose flush block lies beyond the last block) ----
+    if (c.to_hbm) {
+        for (int cb = nblocks * kBlk - 80; cb < W; cb += kBlk) {
+            if (cb < 0) continue;
+            PSA_COMPILER_BARRIER();
+            const int col = cb + lane;
+            if (lane < kBlk && col < W) {
+                const int vs = lds.stage[wv][(col + 64) & 31].y;
+                const int ds = lds.stage[wv][(col + 65) & 31].x;
+                store_granule(c.gout + col, (c.tag_out << 32) | ((unsigned)ds << 2) | (unsigned)(vs - ds));
+            }
+        }
+    }
+    // ---- right boundary / final triple: second pass over the superblocks in which the lanes pass column W-1 ----
+    if (REPLAY && capture && !run_capture_pass<CODES, DENSE>(c, lds, p, capture_lo, p.Q)) return;
     if (row_ok) {
         const int bias = (int)(3 * (i + c0 + W));
         if (p.right && p.right_done) {   // read by the next stripe inside this launch: write through
@@ -777,32 +836,6 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left before the flag does
         if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-
-#ifdef PSA_FILL_STATS
-    if (lane == 0) {
-        const unsigned long long st_end = wall_clock64();
-        unsigned long long* stats = (unsigned long long*)(p.ticket + 48);
-        if (wv == 0) { atomicAdd(stats + 0, st_start - st_entry); atomicAdd(stats + 1, st_end - st_start); }
-        if (wv == kNW - 1 || s == strips - 1) atomicAdd(stats + 2, st_end - st_entry);
-    }
-#endif
-    if (p.prof && lane == 0) {
-        p.prof[4 * s + 1] = wall_clock64();
-        p.prof[4 * s + 3] = ((u64)c.wait_room << 32) | c.wait_in;
-    }
-    // ---- trailing granule group (columns whose flush block lies beyond the last block) ----
-    if (c.to_hbm) {
-        for (int cb = nblocks * kBlk - 80; cb < W; cb += kBlk) {
-            if (cb < 0) continue;
-            PSA_COMPILER_BARRIER();
-            const int col = cb + lane;
-            if (lane < kBlk && col < W) {
-                const int vs = lds.stage[wv][(col + 64) & 31].y;
-                const int ds = lds.stage[wv][(col + 65) & 31].x;
-                store_granule(c.gout + col, (c.tag_out << 32) | ((unsigned)ds << 2) | (unsigned)(vs - ds));
-            }
-        }
-    }
 }
 
 // One pair (or the stripes of one pair) per launch: one workgroup per CU, one wavefront per SIMD.  Every strip is
@@ -811,7 +844,14 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
 // dynamic-LDS keep-out keeps a second workgroup off the CU.
 template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void fill_strips_v2(FillBatch B) {
-    fill_strips_body<CODES, false>(B);
+    fill_strips_body<CODES, false, false>(B);
+}
+// The same for launches in which stripes have a right boundary: capturing strips take the second pass (run_capture_pass).
+// A kernel of its own because the steady loop that looks for the superblock to keep its state at compiles to code
+// that costs a lone pair 1 % (7.07 against 6.99 ms), which the launches without right boundaries need not pay.
+template <bool CODES>
+__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void fill_strips_v2_edges(FillBatch B) {
+    fill_strips_body<CODES, false, true>(B);
 }
 // Independent pairs in one launch: the chains of different pairs do not wait for each other, and a lone
 // wavefront uses less than half of its SIMD's issue slots (one instruction per 4.7 cycles, 12.5 of 21 of them
@@ -820,7 +860,7 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))
 // a lone pair, which is why the sparse kernel stays).
 template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fill_strips_v2_dense(FillBatch B) {
-    fill_strips_body<CODES, true>(B);
+    fill_strips_body<CODES, true, false>(B);
 }
 
 // ---- boundary chunks of a flagged fill (psa_stripe_fill_flagged: one launch over all rows of a stripe whose left

@@ -345,10 +345,17 @@ int launch_fill_v2(const psa::FillArgs2* jobs, int njobs, const uint32_t* order_
                    unsigned* ticket_dev, bool with_codes, size_t keepout_bytes, hipStream_t st, bool dense = false) {
     static bool attr_set[2] = {false, false};
     if (!attr_set[with_codes]) {   // dynamic LDS beyond 64 KB has to be allowed once per kernel
-        if (with_codes) HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
-        else HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
+        if (with_codes) {
+            HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2_edges<true>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
+        } else {
+            HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
+            HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2_edges<false>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
+        }
         attr_set[with_codes] = true;
     }
+    bool edges = false;   // a right boundary somewhere: the kernel whose capturing strips take a second pass
+    for (int j = 0; j < njobs; ++j) edges = edges || jobs[j].base.right != nullptr;
     psa::FillBatch fb;
     memset(&fb, 0, sizeof fb);
     for (int j = 0; j < njobs; ++j) fb.job[j] = jobs[j];
@@ -356,6 +363,9 @@ int launch_fill_v2(const psa::FillArgs2* jobs, int njobs, const uint32_t* order_
     if (dense) {   // independent pairs: two workgroups per CU (PSA_FILL_DENSE=0: the one-wave-per-SIMD kernel)
         if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2_dense<true>, dim3(total_groups), dim3(psa::kNW * 64), psa::kKeepoutDenseBytes, st, fb);
         else hipLaunchKernelGGL(psa::fill_strips_v2_dense<false>, dim3(total_groups), dim3(psa::kNW * 64), psa::kKeepoutDenseBytes, st, fb);
+    } else if (edges) {
+        if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2_edges<true>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
+        else hipLaunchKernelGGL(psa::fill_strips_v2_edges<false>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
     } else if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
     else hipLaunchKernelGGL(psa::fill_strips_v2<false>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
     HIP_TRY(hipGetLastError());
