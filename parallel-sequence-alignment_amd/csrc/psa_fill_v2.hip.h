@@ -792,6 +792,25 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         for (int sb = 0; sb < p.Q; ++sb)
             if (!run_superblock<CODES, DENSE, kGeneric, kAny, kAny>(c, lds, p, sb)) return;
     }
+    if (!REPLAY) {   // (captured in line: out with it at once, as this kernel always did)
+        if (row_ok) {
+            const int bias = (int)(3 * (i + c0 + W));
+            if (p.right && p.right_done) {   // read by the next stripe inside this launch: write through
+                __hip_atomic_store(p.right + c.y_row, c.S.r1 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.right + R + c.y_row, c.S.r2 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.right + 2 * R + c.y_row, c.S.r3 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (p.right) {
+                p.right[c.y_row] = c.S.r1 - bias; p.right[R + c.y_row] = c.S.r2 - bias; p.right[2 * R + c.y_row] = c.S.r3 - bias;
+            }
+            if (i == p.n) {
+                p.final_triple[0] = c.S.r1 - bias; p.final_triple[1] = c.S.r2 - bias; p.final_triple[2] = c.S.r3 - bias;
+            }
+        }
+        if (p.right_done) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left before the flag does
+            if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 #ifdef PSA_FILL_STATS
     if (lane == 0) {
         const unsigned long long st_end = wall_clock64();
@@ -819,22 +838,24 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
     }
     // ---- right boundary / final triple: second pass over the superblocks in which the lanes pass column W-1 ----
     if (REPLAY && capture && !run_capture_pass<CODES, DENSE>(c, lds, p, capture_lo, p.Q)) return;
-    if (row_ok) {
-        const int bias = (int)(3 * (i + c0 + W));
-        if (p.right && p.right_done) {   // read by the next stripe inside this launch: write through
-            __hip_atomic_store(p.right + c.y_row, c.S.r1 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.right + R + c.y_row, c.S.r2 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(p.right + 2 * R + c.y_row, c.S.r3 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (p.right) {
-            p.right[c.y_row] = c.S.r1 - bias; p.right[R + c.y_row] = c.S.r2 - bias; p.right[2 * R + c.y_row] = c.S.r3 - bias;
+    if (REPLAY) {
+        if (row_ok) {
+            const int bias = (int)(3 * (i + c0 + W));
+            if (p.right && p.right_done) {   // read by the next stripe inside this launch: write through
+                __hip_atomic_store(p.right + c.y_row, c.S.r1 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.right + R + c.y_row, c.S.r2 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.right + 2 * R + c.y_row, c.S.r3 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (p.right) {
+                p.right[c.y_row] = c.S.r1 - bias; p.right[R + c.y_row] = c.S.r2 - bias; p.right[2 * R + c.y_row] = c.S.r3 - bias;
+            }
+            if (i == p.n) {
+                p.final_triple[0] = c.S.r1 - bias; p.final_triple[1] = c.S.r2 - bias; p.final_triple[2] = c.S.r3 - bias;
+            }
         }
-        if (i == p.n) {
-            p.final_triple[0] = c.S.r1 - bias; p.final_triple[1] = c.S.r2 - bias; p.final_triple[2] = c.S.r3 - bias;
+        if (p.right_done) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left before the flag does
+            if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    }
-    if (p.right_done) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left before the flag does
-        if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
