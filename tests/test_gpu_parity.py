@@ -73,6 +73,26 @@ def test_random_vs_oracle_tile_edges(alpha):
         assert psa_amd.score(a, b, 1) == sc
 
 
+def test_right_boundary_second_pass_widths():
+    """Stripes with a right boundary take their values at column W-1 in a second pass over their last one or two
+    superblocks (fill_strips_v2_edges, run_capture_pass): stripe widths around the multiples of 64 from 128 up (one or
+    two superblocks to repeat, the capturing superblock the head's neighbour), row counts that leave the last strip
+    partly empty, with and without winner codes; every stripe count against the oracle (simple.cpp:136-154, 215-235)."""
+    rng = np.random.default_rng(777)
+    for alpha in (4, 20):
+        for W in (128, 129, 191, 192, 193, 255, 256, 257, 320, 383, 385):
+            for p, n in ((2, 130), (3, 64), (2, 449)):
+                m = W * p + int(rng.integers(0, p))          # (the last stripe takes the remainder, simple.cpp:92-99)
+                a = rng.integers(65, 65 + alpha, n).astype(np.uint8)
+                b = rng.integers(65, 65 + alpha, m).astype(np.uint8)
+                sc, ai, bj = O.align(a, b)
+                sc_p, triple_p = psa_amd.score(a, b, p, triple=True)
+                sc_1, triple_1 = psa_amd.score(a, b, 1, triple=True)
+                assert sc_p == sc and triple_p == triple_1, (alpha, W, p, n)
+                res = psa_amd.align(a, b, p)
+                assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (alpha, W, p, n)
+
+
 def test_block_indel_walks():
     """Conserved blocks separated by alternating long insertions in A and in B: the walk alternates diagonal
     runs with horizontal and vertical runs of 100-170 cells, which moves it through the traceback's tile
