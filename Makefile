@@ -8,9 +8,27 @@ HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-result
 
 all: $(LIB) simple oracle
 
-$(LIB): $(PKG)/csrc/psa_hip.hip $(wildcard $(PKG)/csrc/*.h) include/psa.h
+# One object per translation unit: a change to one kernel family recompiles only that family (make -j builds them
+# side by side; the fill kernels with and without winner codes are the two long ones).
+CS      := $(PKG)/csrc
+OBJDIR  := build/obj
+OBJS    := $(addprefix $(OBJDIR)/,psa_hip.o psa_fill_codes.o psa_fill_score.o psa_trace.o psa_batch.o)
+COMMON  := $(CS)/psa_args.hip.h $(CS)/psa_device.hip.h $(CS)/psa_launch.h $(CS)/psa_host.h include/psa.h
+FILLH   := $(CS)/psa_fill_tu.hip.h $(CS)/psa_fill_v2.hip.h $(CS)/psa_fill_v1.hip.h
+
+$(OBJDIR)/psa_hip.o: $(CS)/psa_hip.hip $(COMMON)
+$(OBJDIR)/psa_fill_codes.o: $(CS)/psa_fill_codes.hip $(FILLH) $(COMMON)
+$(OBJDIR)/psa_fill_score.o: $(CS)/psa_fill_score.hip $(FILLH) $(CS)/psa_fill_aux.hip.h $(COMMON)
+$(OBJDIR)/psa_trace.o: $(CS)/psa_trace.hip $(CS)/psa_trace1.hip.h $(CS)/psa_trace2.hip.h $(COMMON)
+$(OBJDIR)/psa_batch.o: $(CS)/psa_batch.hip $(CS)/psa_batch.hip.h $(COMMON)
+
+$(OBJDIR)/%.o:
+	mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+
+$(LIB): $(OBJS)
 	mkdir -p $(PKG)/lib
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(PKG)/csrc/psa_hip.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(OBJS)
 
 simple: $(PKG)/host/simple_main.cpp $(LIB) include/psa.h
 	$(HIPCC) -O2 -std=c++17 -o $@ $(PKG)/host/simple_main.cpp -L$(PKG)/lib -lpsa_hip -Wl,-rpath,'$$ORIGIN/$(PKG)/lib'
@@ -19,7 +37,7 @@ oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -rf $(PKG)/lib simple
+	rm -rf $(PKG)/lib simple $(OBJDIR)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -7,28 +7,9 @@
 // trails the reader.  No hand-off between wavefronts, no HBM traffic beyond the sequences and
 // one score per pair: inter-sequence parallelism fills the chip (up to 32 waves per CU).
 #pragma once
-#include "psa_device.hip.h"
+#include "psa_args.hip.h"
 
 namespace psa {
-
-constexpr int kBatchWaves = 4;      // waves per workgroup
-constexpr int kBatchMaxLen = 1024;  // longest B the LDS row buffer holds; longer pairs use psa_score
-constexpr int32_t kBatchSkipped = INT32_MIN;   // score slot of a pair the kernel did not align (B longer than max_b)
-
-struct BatchArgs {
-    const uint8_t* seqs;
-    const int64_t* offsets;
-    const int32_t* pairs;
-    int64_t npairs;
-    int32_t* scores;
-    unsigned* next_pair;   // work counter, zeroed before the launch
-    int max_b;             // longest second sequence in the batch, rounded up to a multiple of 64
-};
-
-// dynamic LDS per wave: row buffer (slot s = (D of column s-65, V of column s-64), as in fill v2),
-// B bytes with 128 bytes of padding in front, and a dump for the lanes that publish nothing
-__host__ __device__ inline int batch_row_slots(int max_b) { return max_b + 160; }
-__host__ __device__ inline int batch_wave_bytes(int max_b) { return batch_row_slots(max_b) * 8 + (max_b + 256) + 112 * 4; }
 
 // How a block of 16 steps treats lanes that are outside the pair's columns (as fill_strips_v2):
 //   kBSteady  every lane is inside (t0 >= 64, t0 + 16 <= nB - 1): no predication at all

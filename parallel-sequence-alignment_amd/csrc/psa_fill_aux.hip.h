@@ -1,0 +1,93 @@
+// psa_fill_aux.hip.h -- the small kernels around the fill: FASTA-to-device encoding (symbol ids of A, the
+// per-symbol substitution table of a stripe's B) and the boundary chunks of a flagged fill.  Compiled in ONE
+// translation unit (psa_fill_score.hip).
+#pragma once
+#include "psa_args.hip.h"
+
+namespace psa {
+
+// ---- alphabet + table construction (FASTA-to-device encoding) ----
+__global__ void alphabet_presence(const uint8_t* a, int64_t n, unsigned* present /*[256]*/) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) present[a[i]] = 1u;
+}
+// meta[0] = number of distinct symbols; map[byte] = id (in byte order), inv[id] = byte
+__global__ void alphabet_compact(const unsigned* present, unsigned* meta, uint8_t* map, uint8_t* inv) {
+    if (threadIdx.x != 0) return;
+    unsigned k = 0;
+    for (int b = 0; b < 256; ++b) {
+        if (present[b]) {
+            map[b] = (uint8_t)(k < (unsigned)kMaxSym ? k : 0);
+            if (k < (unsigned)kMaxSym) inv[k] = (uint8_t)b;
+            ++k;
+        }
+    }
+    meta[0] = k;
+}
+__global__ void encode_rows(const uint8_t* a, int64_t n, const uint8_t* map, uint8_t* ids) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ids[i] = map[a[i]];
+}
+__global__ void build_eqtab(const uint8_t* b, int W, const unsigned* meta, const uint8_t* inv, uint32_t* tab,
+                            int pitch) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;  // word index inside the row
+    const unsigned sym = blockIdx.y;
+    if (w >= pitch) return;
+    uint32_t word = 0x06060606u;
+    if (sym < meta[0] && sym < (unsigned)kMaxSym) {
+        const int c0 = (w - kTabPad) * 4;
+        const unsigned ch = inv[sym];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            if (c >= 0 && c < W && b[c] == ch) word += 2u << (8 * k);
+        }
+    }
+    tab[(size_t)sym * pitch + w] = word;
+}
+
+// ---- boundary chunks of a flagged fill (psa_stripe_fill_flagged: one launch over all rows of a stripe whose left
+// boundary arrives, and whose right boundary leaves, in row chunks while the launch runs) ----
+// packed[k][y] (k < 3, y < rows) -> plane[k * n + r0 + y].  Stored past this CU's cache: the fill reads them with
+// device-scope loads once it has seen the flags, which edge_flags raises in a launch of its own behind this one.
+__global__ void edge_scatter(const int32_t* packed, int64_t r0, int64_t rows, int64_t n, int32_t* plane) {
+    const int64_t total = 3 * rows, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t k = e / rows, y = e - k * rows;
+        __hip_atomic_store(plane + k * n + r0 + y, packed[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ void edge_flags(uint32_t* flags, unsigned count) {
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < count) __hip_atomic_store(flags + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Waits until the fill has raised the flag of EVERY strip of the chunk, then plane[k * n + r0 + y] -> packed[k][y].
+// (Strips do not raise their flags in order: a strip with a right boundary raises its flag only after its second,
+// off-chain pass over its last superblocks -- run_capture_pass, ~7 us -- while the strip below finishes its main pass
+// 3 us after it; a wave slowed in that replay can be overtaken.  So each thread polls flags of its own and the block
+// goes on when all of them are up.)  Gives up (leaving packed as it is) when the fill has given up or after 60 s, and
+// says so in the stripe's abort word.
+__global__ void edge_gather(const int32_t* plane, const uint32_t* done, int64_t r0, int64_t rows, int64_t n, int32_t* packed,
+                            unsigned* abort_flag) {
+    const int64_t f0 = r0 / 64, f1 = (r0 + rows - 1) / 64;
+    const unsigned long long t0 = wall_clock64();
+    int good = 1;
+    for (int64_t f = f0 + threadIdx.x; f <= f1 && good; f += blockDim.x) {
+        while (__hip_atomic_load(done + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(127);
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 2 * kSpinTicks) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                good = 0;
+                break;
+            }
+        }
+    }
+    if (!__syncthreads_and(good)) return;
+    const int64_t total = 3 * rows, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int64_t k = e / rows, y = e - k * rows;
+        packed[e] = __hip_atomic_load(plane + k * n + r0 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace psa

@@ -1,23 +1,28 @@
 // psa_fill_v2.hip.h -- the production fill kernel for gfx950 (alphabets of <= 32 symbols).
 //
-// Same mathematics and the same outputs as fill_strips_v1 (psa_kernels.hip.h), organised for
-// a short dependent instruction stream per anti-diagonal step, because at 2^16 x 2^16 the
-// fill is bound by the length of the dependency chain (N + M steps), not by throughput:
-//   * one workgroup = kNW wavefronts = kNW consecutive strips of 64 rows; strip w hands its
-//     last row to strip w+1 through a ring in LDS (slot per column, flow-controlled), only the
-//     last strip of a workgroup publishes through HBM granules (as v1 does for every strip);
-//   * substitution scores come from a per-symbol table of 4-bit entries (6 or 8, the biased
-//     mismatch / match score) built once per stripe: one v_bfe_u32 per step instead of
-//     shifting B through the lanes and comparing;
-//   * lane 0's inputs (row above the strip) are pre-loaded, 16 steps at a time, into the
-//     destination registers of the DPP moves: a DPP wave_shr:1 leaves lane 0's destination
-//     untouched, so the per-step code has no special case for the strip's first row;
-//   * winner bits are shifted into per-lane accumulators with v_cmp + v_addc_co_u32
-//     (acc = 2*acc + bit) and leave as 16-byte-per-lane coalesced stores, layout as v1;
-//   * steps run in blocks of 16; blocks in which every lane is inside the stripe take the
-//     unpredicated path, the 64-step head and tail of a strip take a predicated one.
+// Same mathematics and the same outputs as fill_strips_v1 (psa_fill_v1.hip.h), organised for a short
+// dependent instruction stream per anti-diagonal step: at 2^16 x 2^16 one pair is bound by the length of
+// its dependency chain (N + M steps), a launch of many pairs by instruction issue.
+//   * one workgroup = kNW wavefronts = kNW consecutive strips of 64 rows; strip w hands its last row to
+//     strip w+1 through a ring in LDS (slot per column, flow-controlled by two LDS counters), only the last
+//     strip of a workgroup publishes through HBM granules (as v1 does for every strip);
+//   * substitution scores come from a per-symbol table of BYTES (6 or 8, the biased mismatch / match score;
+//     four columns per word) built once per stripe (psa_fill_aux.hip.h): the step adds the byte to the
+//     diagonal input with an SDWA source select (v_add_u32_sdwa ... src1_sel:BYTE_k) -- no extract, no
+//     compare, no B residues travelling through the lanes; table words are requested 64 steps ahead;
+//   * lane 0's inputs (row above the strip) are pre-loaded, 16 steps at a time, into the destination
+//     registers of the DPP moves: a DPP wave_shr:1 leaves lane 0's destination untouched, so the per-step
+//     code has no special case for the strip's first row;
+//   * the winner code of a cell is ONE byte, (11 D + 4 H' + V') & 0xff (psa_device.hip.h): v_lshl_add_u32,
+//     v_mad_u32_u24 and a v_alignbit_b32 that shifts it into the word being collected; four steps fill a
+//     word, 64 steps four words per lane, which leave as 16-byte-per-lane coalesced stores (layout as v1);
+//   * lane 63's row leaves as one 16-byte LDS write per two steps (step16);
+//   * steps run in blocks of 16 inside superblocks of 64; blocks in which every lane is inside the stripe
+//     take the unpredicated path compiled per strip role, the 64-step head takes a predicated one, and the
+//     values at the stripe's last column are captured either in line (run_tail) or in a second pass off
+//     the dependency chain (run_capture_pass).
 #pragma once
-#include "psa_kernels.hip.h"
+#include "psa_fill_v1.hip.h"
 
 namespace psa {
 
@@ -36,84 +41,8 @@ namespace psa {
 // HBM-fed strip 8 % slower than the LDS-fed ones, and the slowest strip sets the pace of its chain.
 constexpr int kGranCols = PSA_GRAN_COLS;
 constexpr int kGDist = PSA_GDIST;  // granule requests run this many blocks ahead (1, 2 or 4)
-// Dynamic LDS a fill workgroup is launched with and never uses (see fill_strips_v2).  One pair alone: 96 KB, so that
-// neither a second fill workgroup nor a traceback walk (70 KB) fits on the CU beside it.  Several pairs in one
-// launch: the stripes of ONE pair 70 KB -- still no second fill workgroup (2 x 82 KB > 160 KB), but walks find
-// room beside it (82 + 70 KB); independent pairs (fill_strips_v2_dense) 16 KB: two workgroups per CU, limited by
-// their registers, and a walk's workgroup beside them where registers allow.
-constexpr int kKeepoutAloneBytes = 96 * 1024;
-constexpr int kKeepoutManyBytes = 70 * 1024;
-constexpr int kKeepoutDenseBytes = 16 * 1024;
-constexpr int kFrontWord = 32;  // control block: [0] ticket, [1] abort flag, [32] front (own cache line)
-constexpr int kNW = 4;         // strips (wavefronts) per workgroup
 constexpr int kRing = 256;     // LDS ring slots per strip boundary (8 bytes each)
 constexpr int kBlk = 16;       // steps per block
-constexpr int kMaxSym = 32;    // rows of the substitution table
-constexpr int kTabPad = 16;    // table words (8 columns each) of padding in front of a row
-
-struct FillArgs2 {
-    FillArgs base;
-    const uint8_t* a_ids;     // symbol id (< kMaxSym) of every row of A
-    const uint32_t* eqtab;    // [kMaxSym][tab_pitch] words, byte c%4 of word kTabPad + c/4 = score(sym, B[c]): a byte, so that
-                              // the step adds it with an SDWA byte select and needs no extract
-    int tab_pitch;
-};
-
-// One launch can fill several stripes at once -- of different pairs, or the column stripes of one pair.
-// The workgroups draw tickets from one counter and order[ticket] names (job, group of 4 strips).  The host
-// lays the order out so that every job advances at the pace of its own dependency chain (independent
-// pairs: round-robin; stripes of one pair: stripe g+1 trails stripe g by the time a strip takes) and
-// together they keep every CU busy, which one 2^16 pair alone cannot (its chain is n + m steps long
-// whatever the hardware).  A workgroup only ever waits for workgroups with lower tickets, which run
-// already or have finished: no assumption on dispatch order or residency.
-constexpr int kMaxJobs = 16;
-constexpr int kOrderJobShift = 24;   // order[t] = job << 24 | group
-struct FillBatch {
-    FillArgs2 job[kMaxJobs];
-    int njobs;
-    const uint32_t* order;        // null: one job, group = ticket
-    unsigned* ticket;             // launch-wide ticket counter, zeroed before the launch
-};
-
-// ---- alphabet + table construction (FASTA-to-device encoding) ----
-__global__ void alphabet_presence(const uint8_t* a, int64_t n, unsigned* present /*[256]*/) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) present[a[i]] = 1u;
-}
-// meta[0] = number of distinct symbols; map[byte] = id (in byte order), inv[id] = byte
-__global__ void alphabet_compact(const unsigned* present, unsigned* meta, uint8_t* map, uint8_t* inv) {
-    if (threadIdx.x != 0) return;
-    unsigned k = 0;
-    for (int b = 0; b < 256; ++b) {
-        if (present[b]) {
-            map[b] = (uint8_t)(k < (unsigned)kMaxSym ? k : 0);
-            if (k < (unsigned)kMaxSym) inv[k] = (uint8_t)b;
-            ++k;
-        }
-    }
-    meta[0] = k;
-}
-__global__ void encode_rows(const uint8_t* a, int64_t n, const uint8_t* map, uint8_t* ids) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ids[i] = map[a[i]];
-}
-__global__ void build_eqtab(const uint8_t* b, int W, const unsigned* meta, const uint8_t* inv, uint32_t* tab,
-                            int pitch) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;  // word index inside the row
-    const unsigned sym = blockIdx.y;
-    if (w >= pitch) return;
-    uint32_t word = 0x06060606u;
-    if (sym < meta[0] && sym < (unsigned)kMaxSym) {
-        const int c0 = (w - kTabPad) * 4;
-        const unsigned ch = inv[sym];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = c0 + k;
-            if (c >= 0 && c < W && b[c] == ch) word += 2u << (8 * k);
-        }
-    }
-    tab[(size_t)sym * pitch + w] = word;
-}
 
 // ---- per-workgroup LDS ----
 struct __attribute__((aligned(128))) FillLds {
@@ -218,7 +147,6 @@ __device__ __forceinline__ void lds_post(int* p, int v) {
 // with several kernels or processes sharing the GPU a wait can be long in iterations without
 // anything being wrong.  Looked at once per 1024 polls, together with the abort flag (rarely:
 // hundreds of waiting waves share that one address).
-constexpr unsigned long long kSpinTicks = 30ull * 100000000ull;   // 30 s
 struct Spin {
     unsigned n = 0;
     unsigned long long t0 = 0;
@@ -882,50 +810,6 @@ __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))
 template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void fill_strips_v2_dense(FillBatch B) {
     fill_strips_body<CODES, true, false>(B);
-}
-
-// ---- boundary chunks of a flagged fill (psa_stripe_fill_flagged: one launch over all rows of a stripe whose left
-// boundary arrives, and whose right boundary leaves, in row chunks while the launch runs) ----
-// packed[k][y] (k < 3, y < rows) -> plane[k * n + r0 + y].  Stored past this CU's cache: the fill reads them with
-// device-scope loads once it has seen the flags, which edge_flags raises in a launch of its own behind this one.
-__global__ void edge_scatter(const int32_t* packed, int64_t r0, int64_t rows, int64_t n, int32_t* plane) {
-    const int64_t total = 3 * rows, stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t k = e / rows, y = e - k * rows;
-        __hip_atomic_store(plane + k * n + r0 + y, packed[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-__global__ void edge_flags(uint32_t* flags, unsigned count) {
-    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < count) __hip_atomic_store(flags + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// Waits until the fill has raised the flag of the chunk's last strip (strips end in order), then
-// plane[k * n + r0 + y] -> packed[k][y].  Gives up (leaving packed as it is) when the fill has given up or after 60 s,
-// and says so in the stripe's abort word.
-__global__ void edge_gather(const int32_t* plane, const uint32_t* done, int64_t r0, int64_t rows, int64_t n, int32_t* packed,
-                            unsigned* abort_flag) {
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-        const uint32_t* f = done + (r0 + rows - 1) / 64;
-        const unsigned long long t0 = wall_clock64();
-        int good = 1;
-        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(127);
-            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 2 * kSpinTicks) {
-                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                good = 0;
-                break;
-            }
-        }
-        ok = good;
-    }
-    __syncthreads();
-    if (!ok) return;
-    const int64_t total = 3 * rows, stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int64_t k = e / rows, y = e - k * rows;
-        packed[e] = __hip_atomic_load(plane + k * n + r0 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 }  // namespace psa

@@ -1,7 +1,5 @@
 // psa_hip.hip -- C ABI (include/psa.h) over the gfx950 kernels.  No CPU fallback: every
 // compute entry point needs a HIP device and fails with PSA_E_NO_DEVICE otherwise.
-#include "../../include/psa.h"
-
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -14,11 +12,10 @@
 #include <string>
 #include <vector>
 
-#include "psa_fill_v2.hip.h"
-#include "psa_batch.hip.h"
-#include "psa_trace2.hip.h"
+#include "psa_host.h"
+#include "psa_launch.h"
 
-namespace {
+namespace psa_host {
 
 thread_local std::string g_err;
 
@@ -32,14 +29,6 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return fail(e_ == hipErrorOutOfMemory ? PSA_E_NOMEM : PSA_E_HIP, "%s failed: %s", \
-                        #expr, hipGetErrorString(e_));                                       \
-    } while (0)
-
 int need_device() {
     int cnt = 0;
     hipError_t e = hipGetDeviceCount(&cnt);
@@ -48,6 +37,13 @@ int need_device() {
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     return PSA_OK;
 }
+
+}  // namespace psa_host
+
+using psa_host::fail;
+using psa_host::need_device;
+
+namespace {
 
 // simple.cpp:162/166/170: table 1 if t1>=t2 && t1>=t3, else 2 if t2>=t3, else 3.
 int pick3(const int32_t t[3], int32_t* v) {
@@ -67,7 +63,7 @@ constexpr size_t kCtrlBytes = (kCtrlRing + 1) * kCtrlLaunchBytes;
 constexpr int kAbortWord = kCtrlRing * 64;
 constexpr int kCornerSlots = 4;                 // triples at (r0, c0) of the chunks in flight
 constexpr int kFinalWord = 4 * kCornerSlots;    // the final triple lives behind them in `small`
-constexpr size_t kAlphaBytes = 256 * 4 + 16 + 256 + 32;
+using psa::kAlphaBytes;
 
 // The current HIP device is a per-thread setting.  Every call that works on an object makes the object's
 // device current for its own duration and puts the caller's back on return.
@@ -236,19 +232,8 @@ int bind_stripe(psa_stripe* s, int64_t n, int64_t m, int64_t c0, int64_t c1) {
 // FASTA-to-device encoding for the v2 kernel: symbol ids of A, substitution table of B.  nsym_known >= 0:
 // the caller has counted A's distinct residues itself (host sequences) and no device round trip is needed.
 int rebuild_tables(psa_stripe* s, hipStream_t st, int nsym_known) {
-    unsigned* present = (unsigned*)s->alpha;
-    unsigned* meta = present + 256;
-    uint8_t* map = (uint8_t*)(meta + 4);
-    uint8_t* inv = map + 256;
-    HIP_TRY(hipMemsetAsync(s->alpha, 0, kAlphaBytes, st));
-    const int blocks = (int)std::min<int64_t>(1024, (s->n + 255) / 256);
-    hipLaunchKernelGGL(psa::alphabet_presence, dim3(blocks), dim3(256), 0, st, s->a_dev, s->n, present);
-    hipLaunchKernelGGL(psa::alphabet_compact, dim3(1), dim3(64), 0, st, present, meta, map, inv);
-    hipLaunchKernelGGL(psa::encode_rows, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, st, s->a_dev, s->n, map,
-                       s->a_ids);
-    hipLaunchKernelGGL(psa::build_eqtab, dim3((unsigned)((s->tab_pitch + 255) / 256), psa::kMaxSym), dim3(256), 0, st,
-                       s->b_dev, s->W, meta, inv, s->eqtab, s->tab_pitch);
-    HIP_TRY(hipGetLastError());
+    unsigned* meta = psa::alpha_meta(s->alpha);
+    HIP_TRY(psa::launch_tables(s->a_dev, s->n, s->b_dev, s->W, s->alpha, s->a_ids, s->eqtab, s->tab_pitch, st));
     unsigned k = (unsigned)nsym_known;
     if (nsym_known < 0) {
         HIP_TRY(hipMemcpyAsync(&k, meta, sizeof k, hipMemcpyDeviceToHost, st));
@@ -343,32 +328,16 @@ unsigned groups_of(const psa::FillArgs2& j) {
 // One launch of fill_strips_v2 over up to kMaxJobs stripes.  order_dev: ticket -> job << 24 | group (null: one job).
 int launch_fill_v2(const psa::FillArgs2* jobs, int njobs, const uint32_t* order_dev, unsigned total_groups,
                    unsigned* ticket_dev, bool with_codes, size_t keepout_bytes, hipStream_t st, bool dense = false) {
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[with_codes]) {   // dynamic LDS beyond 64 KB has to be allowed once per kernel
-        if (with_codes) {
-            HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
-            HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2_edges<true>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
-        } else {
-            HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
-            HIP_TRY(hipFuncSetAttribute((const void*)psa::fill_strips_v2_edges<false>, hipFuncAttributeMaxDynamicSharedMemorySize, psa::kKeepoutAloneBytes));
-        }
-        attr_set[with_codes] = true;
-    }
     bool edges = false;   // a right boundary somewhere: the kernel whose capturing strips take a second pass
     for (int j = 0; j < njobs; ++j) edges = edges || jobs[j].base.right != nullptr;
     psa::FillBatch fb;
     memset(&fb, 0, sizeof fb);
     for (int j = 0; j < njobs; ++j) fb.job[j] = jobs[j];
     fb.njobs = njobs; fb.order = order_dev; fb.ticket = ticket_dev;
-    if (dense) {   // independent pairs: two workgroups per CU (PSA_FILL_DENSE=0: the one-wave-per-SIMD kernel)
-        if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2_dense<true>, dim3(total_groups), dim3(psa::kNW * 64), psa::kKeepoutDenseBytes, st, fb);
-        else hipLaunchKernelGGL(psa::fill_strips_v2_dense<false>, dim3(total_groups), dim3(psa::kNW * 64), psa::kKeepoutDenseBytes, st, fb);
-    } else if (edges) {
-        if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2_edges<true>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
-        else hipLaunchKernelGGL(psa::fill_strips_v2_edges<false>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
-    } else if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v2<true>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
-    else hipLaunchKernelGGL(psa::fill_strips_v2<false>, dim3(total_groups), dim3(psa::kNW * 64), keepout_bytes, st, fb);
-    HIP_TRY(hipGetLastError());
+    // independent pairs: two workgroups per CU (PSA_FILL_DENSE=0: the one-wave-per-SIMD kernel)
+    const int kernel = dense ? psa::kFillDense : edges ? psa::kFillEdges : psa::kFillSparse;
+    if (with_codes) HIP_TRY(psa::launch_fill_v2_codes(fb, total_groups, kernel, keepout_bytes, st));
+    else HIP_TRY(psa::launch_fill_v2_score(fb, total_groups, kernel, keepout_bytes, st));
     return PSA_OK;
 }
 
@@ -396,9 +365,8 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
         // the kernels that bring it -- collective library, psa_edge_post -- 77 KB of every CU's LDS)
         const size_t keepout = (o.left_done || o.right_done) ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes;
         if (int rc = launch_fill_v2(&fb, 1, nullptr, groups_of(fb), fb.base.ticket, with_codes, keepout, st)) return rc;
-    } else if (with_codes) hipLaunchKernelGGL(psa::fill_strips_v1<true>, dim3(strips), dim3(64), 0, st, fb.base);
-    else hipLaunchKernelGGL(psa::fill_strips_v1<false>, dim3(strips), dim3(64), 0, st, fb.base);
-    HIP_TRY(hipGetLastError());
+    } else if (with_codes) HIP_TRY(psa::launch_fill_v1_codes(fb.base, strips, st));
+    else HIP_TRY(psa::launch_fill_v1_score(fb.base, strips, st));
     HIP_TRY(hipEventRecord(s->ev[1], st));
     s->fill_timed = true;
     if (prof_dev) {  // diagnostic only: dump per-strip start/end ticks and placement
@@ -473,11 +441,10 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     HIP_TRY(hipEventRecord(s->ev[2], st));
     {
         const char* force = getenv("PSA_TRACEBACK_KERNEL");
-        if ((force && !strcmp(force, "v1")) || !walk_fits32(s, ta.Q)) hipLaunchKernelGGL(psa::traceback_v1, dim3(1), dim3(64), 0, st, ta);
-        else if (force && !strcmp(force, "wave1")) hipLaunchKernelGGL(psa::traceback_wave, dim3(1), dim3(64), 0, st, ta);
-        else hipLaunchKernelGGL(psa::traceback_pair, dim3(1), dim3(128), 0, st, ta);
+        const int kind = ((force && !strcmp(force, "v1")) || !walk_fits32(s, ta.Q)) ? psa::kWalkLane
+                         : (force && !strcmp(force, "wave1")) ? psa::kWalkWave : psa::kWalkPair;
+        HIP_TRY(psa::launch_traceback(kind, ta, st));
     }
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev[3], st));
     s->tb_timed = true;
     HIP_TRY(hipMemcpyAsync(state, s->tb_state, sizeof state, hipMemcpyDeviceToHost, st));
@@ -509,7 +476,7 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
 
 extern "C" {
 
-const char* psa_last_error(void) { return g_err.c_str(); }
+const char* psa_last_error(void) { return psa_host::g_err.c_str(); }
 const char* psa_version(void) { return "psa-hip 0.2 (gfx950)"; }
 
 int psa_device_count(void) {
@@ -614,12 +581,7 @@ int psa_edge_post(const int32_t* packed_dev, int64_t r0, int64_t rows, int64_t n
                     (long long)r0, (long long)rows, (long long)n);
     if (r0 + rows < n && (rows & 63)) return fail(PSA_E_ARG, "psa_edge_post: only the last chunk may have a row count off 64");
     hipStream_t st = (hipStream_t)stream;
-    const unsigned blocks = (unsigned)std::min<int64_t>((3 * rows + 255) / 256, 1024);
-    hipLaunchKernelGGL(psa::edge_scatter, dim3(blocks), dim3(256), 0, st, packed_dev, r0, rows, n, left_dev);
-    // (a kernel of its own: everything the scatter stored is visible device-wide when this one starts)
-    const unsigned nflags = (unsigned)((rows + 63) / 64);
-    hipLaunchKernelGGL(psa::edge_flags, dim3((nflags + 255) / 256), dim3(256), 0, st, left_ready + r0 / 64, nflags);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(psa::launch_edge_post(packed_dev, r0, rows, n, left_dev, left_ready, st));
     return PSA_OK;
 }
 
@@ -631,10 +593,7 @@ int psa_edge_take(psa_stripe* s, const int32_t* right_dev, const uint32_t* right
     DeviceGuard g(s->device);
     if (g.rc) return g.rc;
     hipStream_t st = (hipStream_t)stream;
-    const unsigned blocks = (unsigned)std::min<int64_t>((3 * rows + 255) / 256, 64);
-    hipLaunchKernelGGL(psa::edge_gather, dim3(blocks), dim3(256), 0, st, right_dev, right_done, r0, rows, s->n, packed_dev,
-                       s->ctrl + kAbortWord);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(psa::launch_edge_take(right_dev, right_done, r0, rows, s->n, packed_dev, s->ctrl + kAbortWord, st));
     return PSA_OK;
 }
 
@@ -1221,9 +1180,7 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         tb.njobs = nt;
         if (nt > 0) {
             const char* force = getenv("PSA_TRACEBACK_KERNEL");
-            if (force && !strcmp(force, "wave1")) hipLaunchKernelGGL(psa::traceback_wave_many, dim3(nt), dim3(64), 0, st, tb);
-            else hipLaunchKernelGGL(psa::traceback_pair_many, dim3(nt), dim3(128), 0, st, tb);
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(psa::launch_traceback_many((force && !strcmp(force, "wave1")) ? psa::kWalkWave : psa::kWalkPair, tb, nt, st));
         }
     }
     HIP_TRY(hipEventRecord(e->ev[2], st));
@@ -1414,77 +1371,6 @@ int psa_score_batch(const uint8_t* seqs, const int64_t* offsets, int64_t nseqs, 
         if (rc != PSA_OK) return rc;
     }
     return PSA_OK;
-}
-
-int psa_score_batch_dev(const uint8_t* seqs_dev, const int64_t* offsets_dev, const int32_t* pairs_dev, int64_t npairs,
-                        int max_len_b, int32_t* scores_dev, unsigned* counter_dev, void* stream) {
-    if (npairs <= 0) return PSA_OK;
-    if (max_len_b < 0 || max_len_b > psa::kBatchMaxLen)
-        return fail(PSA_E_ARG, "psa_score_batch_dev: max_len_b must be in [0, %d]", psa::kBatchMaxLen);
-    if (!seqs_dev || !offsets_dev || !pairs_dev || !scores_dev || !counter_dev)
-        return fail(PSA_E_ARG, "psa_score_batch_dev: null argument");
-    if (int rc = need_device()) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipMemsetAsync(counter_dev, 0, 256, st));
-    psa::BatchArgs ba;
-    ba.seqs = seqs_dev; ba.offsets = offsets_dev; ba.pairs = pairs_dev; ba.npairs = npairs; ba.scores = scores_dev;
-    ba.next_pair = counter_dev;
-    ba.max_b = std::max(64, ((max_len_b + 63) / 64) * 64);
-    const size_t lds_bytes = (size_t)psa::kBatchWaves * psa::batch_wave_bytes(ba.max_b);
-    int dev = 0, cus = 256;
-    HIP_TRY(hipGetDevice(&dev));
-    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t want = (npairs + psa::kBatchWaves - 1) / psa::kBatchWaves;
-    const unsigned grid = (unsigned)std::min<int64_t>(want, (int64_t)cus * 8);
-    hipLaunchKernelGGL(psa::batch_score_kernel, dim3(grid), dim3(psa::kBatchWaves * 64), lds_bytes, st, ba);
-    HIP_TRY(hipGetLastError());
-    return PSA_OK;
-}
-
-
-}  // extern "C"
-
-// ---- psa_score_batch_dev without any allocation and without a workspace argument ----
-// The batch kernel's scratch -- its work counter, the only device memory it uses beyond inputs and outputs --
-// lives in this file-scope device array (256 bytes on every GPU the library runs on, until the process ends).
-// In host code the array's NAME is only a stand-in: the address kernels and memsets get is the one
-// hipGetSymbolAddress returns for the current device, looked up once per device and kept.
-static __device__ __align__(256) unsigned scratch[64];
-
-namespace {
-constexpr int kMaxScratchDevices = 64;
-constexpr int64_t kNoAllocMaxPairs = 1LL << 30;   // the counter is 32 bits wide; the kernel adds to it once per pair and wave
-unsigned* g_scratch_ptr[kMaxScratchDevices] = {nullptr};
-
-int scratch_for_current_device(unsigned** out) {
-    int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    if (dev < 0 || dev >= kMaxScratchDevices) return fail(PSA_E_ARG, "device %d: only devices 0..%d have a scratch slot", dev, kMaxScratchDevices - 1);
-    unsigned* ptr = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
-    if (!ptr) {   // first call on this device (it is current): ask the runtime where this GPU's copy of the array lies
-        HIP_TRY(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
-        if (!ptr) return fail(PSA_E_HIP, "hipGetSymbolAddress returned a null address for the scratch array");
-        __atomic_store_n(&g_scratch_ptr[dev], ptr, __ATOMIC_RELEASE);   // (two threads racing here store the same address)
-    }
-    *out = ptr;
-    return PSA_OK;
-}
-}  // namespace
-
-extern "C" {
-
-int psa_score_batch_dev_noalloc(const uint8_t* seqs_dev, const int64_t* offsets_dev, const int32_t* pairs_dev, int64_t npairs,
-                                int max_len_b, int32_t* scores_dev, void* stream) {
-    if (npairs <= 0) return PSA_OK;
-    if (npairs > kNoAllocMaxPairs)
-        return fail(PSA_E_ARG, "psa_score_batch_dev_noalloc: %lld pairs exceed the maximum of %lld per call", (long long)npairs,
-                    (long long)kNoAllocMaxPairs);
-    if (int rc = need_device()) return rc;
-    unsigned* ptr = nullptr;
-    if (int rc = scratch_for_current_device(&ptr)) return rc;
-    // (psa_score_batch_dev zeroes the counter it is handed -- here this GPU's scratch, which still holds the
-    // last call's count -- and launches the kernel; it allocates nothing)
-    return psa_score_batch_dev(seqs_dev, offsets_dev, pairs_dev, npairs, max_len_b, scores_dev, ptr, stream);
 }
 
 // simple.cpp:312 + output_alignement (simple.cpp:43-70); both Length lines print al_A's size.

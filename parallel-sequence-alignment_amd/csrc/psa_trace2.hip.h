@@ -1,6 +1,6 @@
 // psa_trace2.hip.h -- the traceback walk with a second wavefront that does the fetching.
 //
-// Same walk, same LDS window and same passes as tb_walk (psa_kernels.hip.h, which stays as the single-wave
+// Same walk, same LDS window and same passes as tb_walk (psa_trace1.hip.h, which stays as the single-wave
 // variant, PSA_TRACEBACK_KERNEL=wave1).  A lone wavefront pays 6-7 cycles for every instruction it issues, and
 // in tb_walk two thirds of the instructions of a tile entry belong to fetching: the cursor along the diagonal,
 // the LDS-DMA issue, the directory update, the residue rings, the counted waits.  Here wave 1 of the workgroup
@@ -24,7 +24,7 @@
 //     cell that needs it is decoded one at a time from global memory (tb_winner, the path of traceback_v1);
 //   * every wait is bounded by wall-clock time: the walker gives up with an error, the fetcher just ends.
 #pragma once
-#include "psa_kernels.hip.h"
+#include "psa_trace1.hip.h"
 
 namespace psa {
 
