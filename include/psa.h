@@ -208,8 +208,9 @@ int psa_stripe_fill_rows(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* l
  * right_done : DEVICE uint32[(n+63)/64], zeroed by the caller; right_done[g] is raised when strip g's rows of
  *              right_dev are written.  psa_edge_take waits (on its stream, on the device) for a chunk's last strip
  *              and packs the chunk as [3][rows] for sending.  NULL: read right_dev after the launch.
- * The fill, the posts and the takes go to three different streams.  A wait that lasts longer than 60 s (a chunk
- * that never arrives) ends the launch; psa_stripe_final then returns PSA_E_KERNEL.
+ * The fill, the posts and the takes go to three different streams.  A strip's wait that lasts longer than 30 s (a
+ * chunk that never arrives) ends the launch (psa_edge_take gives up after 60 s); psa_stripe_final then returns
+ * PSA_E_KERNEL.  psa_edge_take waits for the flag of EVERY strip of its chunk.
  */
 /* A stream (hipStream_t) for the flagged fill.  HIP multiplexes streams onto a few hardware queues (4 by default),
  * and a kernel does not start before the kernel queued ahead of it on the same hardware queue has ended: a flagged
@@ -235,11 +236,23 @@ int psa_stripe_final(psa_stripe* s, void* stream, int32_t triple_out[3]);
 /*
  * Walk the alignment back through this stripe (needs PSA_F_TRACEBACK).  State (i, j, k):
  * cell (i, j) of table k; the first call starts at (n, m, k*) with k* the
- * winning table of the final pick.  The walk proceeds while the predecessor cell lies in
- * this stripe's columns (or on the matrix boundary when c0 == 0) and stops either at the
- * matrix boundary (i == 0 or j == 0) or when the predecessor belongs to the stripe on the
- * left; the state then returned is handed to that stripe.  Columns are APPENDED in walk
- * order (i.e. reversed) to ai/bj (HOST arrays of capacity cap) starting at *len_io.
+ * winning table of the final pick.  Columns are APPENDED in walk order (i.e. reversed) to
+ * ai/bj (HOST arrays of capacity cap) starting at *len_io.
+ *
+ * The hand-over between stripes, exactly (any engine that shares a walk with this one must
+ * follow it; tests/test_distributed.py's CPU stand-in does):
+ *   - a state names a cell whose alignment column has NOT been emitted yet.  One step of the
+ *     walk: the predecessor cell is (pi, pj) = (i - (k != 2), j - (k != 3)); the winner w among
+ *     the predecessor's three tables for aggregate k (simple.cpp:162/166/170 and siblings)
+ *     decides the column -- push (i-1, j-1) / (-1, j-1) / (i-1, -1) for w = 1 / 2 / 3 -- and the
+ *     state becomes (pi, pj, w).  The winner is a property of the PREDECESSOR cell, so a step
+ *     is taken by the stripe that owns the predecessor's column.
+ *   - a stripe with columns (c0, c1] therefore accepts states with c0 < j <= c1 + 1; j == c1 + 1
+ *     only with k in {1, 2} (the cell lies in the stripe on the right, its predecessor in
+ *     column c1 is this stripe's).
+ *   - the walk ends with i == 0 or j == 0 (matrix boundary: finished), or -- when c0 > 0 --
+ *     as soon as pj <= c0: the state returned then has j == c0 + 1 and k in {1, 2} (a vertical
+ *     step never leaves a stripe) and is handed, unchanged, to the stripe on the left.
  */
 int psa_stripe_traceback(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32_t* ai,
                          int32_t* bj, int64_t cap, int64_t* len_io, void* stream);

@@ -364,7 +364,17 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
         // (a flagged fill keeps every CU occupied with strips that wait for their boundary: the smaller keep-out leaves
         // the kernels that bring it -- collective library, psa_edge_post -- 77 KB of every CU's LDS)
         const size_t keepout = (o.left_done || o.right_done) ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes;
-        if (int rc = launch_fill_v2(&fb, 1, nullptr, groups_of(fb), fb.base.ticket, with_codes, keepout, st)) return rc;
+        // One pair alone gets one wavefront per SIMD because its strips are links of ONE chain -- as long as the chain
+        // is what bounds it.  A pair with many more strips than SIMDs and rows long enough for all of them to be in
+        // flight together (2^20 x 2^20: 16 384 strips, each 378 steps behind the one above and a million steps long)
+        // is bound by instruction issue like a launch of independent pairs: two wavefronts per SIMD
+        // (fill_strips_v2_dense).  Whole-stripe launches only: row chunks in flight on two streams must fit the chip
+        // together (distributed.auto_chunk_rows).
+        static const int64_t dense_min_w = [] { const char* e = getenv("PSA_FILL_DENSE_MIN_W"); return e ? atoll(e) : (1LL << 19); }();
+        const unsigned groups = groups_of(fb);
+        const bool dense = r0 == 0 && r1 == s->n && !o.left_done && !o.right_done && !right_dev && !prof_dev &&
+                           groups >= 1024 && fb.base.W >= dense_min_w;
+        if (int rc = launch_fill_v2(&fb, 1, nullptr, groups, fb.base.ticket, with_codes, keepout, st, dense)) return rc;
     } else if (with_codes) HIP_TRY(psa::launch_fill_v1_codes(fb.base, strips, st));
     else HIP_TRY(psa::launch_fill_v1_score(fb.base, strips, st));
     HIP_TRY(hipEventRecord(s->ev[1], st));

@@ -27,6 +27,9 @@ class OracleStripeEngine:
         self.top = np.array([[O.boundary(0, c0 + x)[k] for x in range(self.w + 1)] for k in range(3)], np.int32)
         self.corner = np.array(O.boundary(0, c0), np.int32)
         self.codes = np.zeros((self.n + 1, self.w + 1), np.uint8)
+        # T1,T2,T3 of column c1 for every row: the walk's step INTO this stripe from the right is decided by them
+        self.right_all = np.zeros((3, self.n + 1), np.int32)
+        self.right_all[:, 0] = O.boundary(0, c1)
         self.final_triple = None
 
     def new_edge(self, rows):
@@ -45,6 +48,7 @@ class OracleStripeEngine:
         self.codes[r0 + 1:r1 + 1, 1:] = codes
         self.top = bottom
         self.corner = lf[:, rows].copy()
+        self.right_all[:, r0 + 1:r1 + 1] = rgt[:, 1:]
         if right is not None:
             right.copy_(torch.from_numpy(rgt[:, 1:].reshape(-1).copy()))
         self.final_triple = tuple(int(x) for x in bottom[:, self.w])
@@ -52,19 +56,33 @@ class OracleStripeEngine:
     def final(self):
         return self.final_triple
 
+    @staticmethod
+    def winner_plain(t, kind):
+        """Winner among a source cell's tables for aggregate kind (simple.cpp:162/179/198 tie-break)."""
+        t1, t2, t3 = (int(x) for x in t)
+        if kind == 2:
+            t1, t2, t3 = t1 - 3, t2 - 1, t3 - 3
+        elif kind == 3:
+            t1, t2, t3 = t1 - 3, t2 - 3, t3 - 1
+        if t1 >= t2 and t1 >= t3:
+            return 1
+        return 2 if t2 >= t3 else 3
+
     def traceback(self, i, j, k):
+        """The hand-over convention of include/psa.h (psa_stripe_traceback): a state names a cell whose column
+        is not emitted yet; the stripe that owns the PREDECESSOR's column takes the step."""
         ai, bj = [], []
-        while i > 0 and j > self.c0:   # j == c0: the cell belongs to the stripe on the left
-            w = (int(self.codes[i, j - self.c0]) >> (2 * (k - 1))) & 3
+        while i > 0 and j > 0:
+            pi, pj = i - (k != 2), j - (k != 3)
+            if self.c0 > 0 and pj <= self.c0:
+                break                         # the predecessor belongs to the stripe on the left
+            if j == self.c1 + 1:              # the cell lies in the stripe on the right, its predecessor in column c1
+                w = self.winner_plain(self.right_all[:, pi], k)
+            else:
+                w = (int(self.codes[i, j - self.c0]) >> (2 * (k - 1))) & 3
             ai.append(-1 if w == 2 else i - 1)
             bj.append(-1 if w == 3 else j - 1)
-            if k == 1:
-                i, j = i - 1, j - 1
-            elif k == 2:
-                j -= 1
-            else:
-                i -= 1
-            k = w
+            i, j, k = pi, pj, w
         return i, j, k, np.array(ai, np.int32), np.array(bj, np.int32)
 
     def close(self):

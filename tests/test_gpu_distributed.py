@@ -79,8 +79,10 @@ def _cases(rng, shapes):
 def test_flagged_fill_between_cpu_neighbours(engines):
     """distributed._fill_flagged on the GPU rank: the stripe is one launch, chunks of its left boundary arrive from
     the rank on the left and chunks of its right boundary leave for the rank on the right while it runs."""
-    # (score only: the two engines hand the walk over at different cells -- the fill is what is under test)
-    cases = [(a, b, False) for a, b, _ in _cases(np.random.default_rng(23), ((700, 660, 3), (1500, 1400, 4), (130, 40, 20), (3000, 900, 20)))]
+    # (with the walk: the CPU stand-in follows the hand-over convention of include/psa.h, so HIP and CPU stripes
+    # hand (i, j, k) to each other in both directions)
+    cases = _cases(np.random.default_rng(23), ((700, 660, 3), (1500, 1400, 4), (130, 40, 20), (3000, 900, 20)))
+    cases.append((cases[1][0], cases[1][1], False))
     _run(len(engines), cases, 256, engines)
 
 

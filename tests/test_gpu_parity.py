@@ -191,6 +191,90 @@ def test_full_size_pair_vs_oracle():
     assert not np.any((res.ai < 0) & (res.bj < 0))
 
 
+def _bench_goldens():
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_only.json")))
+    return {(e["slot"], e["n"], e["m"]): e for e in g["bench_pairs"]}
+
+
+def _bench_pair(slot, n=1 << 16, m=1 << 16):
+    k = 16
+    a = psa_amd.synth_protein(0xA0000000 + k + 0x100 * slot, 1 << k)[:n]
+    b = psa_amd.synth_protein(0xB0000000 + k + 0x100 * slot, 1 << k)[:m]
+    return a, b
+
+
+def _columns_md5(res):
+    return hashlib.md5(np.ascontiguousarray(res.ai, np.int32).tobytes() + np.ascontiguousarray(res.bj, np.int32).tobytes()).hexdigest()
+
+
+def test_dense_launch_at_bench_shape_distinct_pairs(golden_dir):
+    """The kernel bench.py times -- fill_strips_v2_dense: ONE launch over 16 pairs of 2^16 x 2^16, 1 024 strips each, two
+    workgroups per CU, ring wrap-around -- at the bench's own shape with a DIFFERENT pair in every slot, two slots of
+    other sizes (titin; 50 000 x 65 536 / 65 536 x 40 000), two launches back to back on two engines as bench.py
+    does.  Every slot: score, alignment length and the md5 of all its columns against the committed restatement-only
+    goldens (tests/golden/oracle_only.json, make_oracle_golden.py --bench-pairs: 'parity unpinned' beyond what
+    test_oracle.py pins the restatement to); four slots column for column against the oracle run here."""
+    gold = _bench_goldens()
+    n = m = 1 << 16
+    ta = np.frombuffer(psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "titin_homo(50).fasta")), np.uint8)
+    tb = np.frombuffer(psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "titin_mus.fasta")), np.uint8)
+    engines = [psa_amd.Many(16, n, m, traceback=True) for _ in range(2)]
+    layouts = []
+    for x in range(2):
+        lay = []
+        for sl in range(16):
+            if sl == 14:
+                lay.append(("titin", ta, tb))
+            elif sl == 15:
+                key = (1, 50000, m) if x == 0 else (2, n, 40000)
+                lay.append((key,) + _bench_pair(*key))
+            else:
+                slot = (sl + 7 * x) % 14            # (the second engine holds the pairs in other slots)
+                lay.append(((slot, n, m),) + _bench_pair(slot))
+        layouts.append(lay)
+    for x, eng in enumerate(engines):
+        for sl, (_, a, b) in enumerate(layouts[x]):
+            eng.set_pair(sl, a, b)
+        eng.launch(engines[x ^ 1])
+    live = {}
+    for x, eng in enumerate(engines):
+        eng.wait()
+        for sl, (key, a, b) in enumerate(layouts[x]):
+            res = eng.result(sl, a.size, b.size)
+            if key == "titin":
+                out = psa_amd.format_result(res, a, b)
+                assert hashlib.md5(out).hexdigest() == "65af487c90fa2638ce05f3a6badbaaea", (x, sl)
+                continue
+            g = gold[key]
+            assert (res.score, len(res.ai), _columns_md5(res)) == (g["score"], g["alignment_len"], g["columns_md5"]), (x, sl, key)
+            if (x, sl) in ((0, 0), (0, 15), (1, 3), (1, 15)):
+                live[(x, sl)] = (a, b, res)
+    for e in engines:
+        e.close()
+    for (x, sl), (a, b, res) in live.items():
+        sc, ai, bj = O.align(a, b, min(16, os.cpu_count() or 1))
+        assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (x, sl)
+
+
+def test_column_stripes_at_metric_sizes(golden_dir):
+    """p > 1 at the sizes the metric is quoted on (simple.cpp:90-99, 136-154, 215-235: the stripes of one pair, here
+    jobs of ONE launch with flags between them): the titin pair with p = 8 against the committed md5 of its stdout,
+    the 2^16 x 2^16 pair with p = 4 and p = 8 column for column against p = 1 and the committed golden."""
+    a = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "titin_homo(50).fasta"))
+    b = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "titin_mus.fasta"))
+    assert hashlib.md5(gpu_stdout(a, b, 8)).hexdigest() == "65af487c90fa2638ce05f3a6badbaaea"
+    g = _bench_goldens()[(0, 1 << 16, 1 << 16)]
+    a, b = _bench_pair(0)
+    ref = psa_amd.align(a, b, 1)
+    assert (ref.score, len(ref.ai), _columns_md5(ref)) == (g["score"], g["alignment_len"], g["columns_md5"])
+    for p in (4, 8):
+        res = psa_amd.align(a, b, p)
+        assert res.score == ref.score and np.array_equal(res.ai, ref.ai) and np.array_equal(res.bj, ref.bj), p
+        assert psa_amd.score(a, b, p) == ref.score
+    psa_amd.release_cache()
+
+
 def test_cli_byte_exact(golden_dir):
     exe = os.path.join(ROOT, "simple")
     assert os.path.exists(exe), "run `make` first"

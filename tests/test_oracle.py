@@ -153,17 +153,31 @@ def test_neighbour_bounds_behind_the_one_byte_codes():
 
 
 def test_restatement_only_goldens_are_what_the_generator_writes(golden_dir):
-    """tests/golden/oracle_only.json (made by make_oracle_golden.py, restatement-only): well-formed, marked, and
-    its titin entry is the md5 the GPU test uses; the 2^16 score is recomputed here (seconds)."""
+    """tests/golden/oracle_only.json (made by make_oracle_golden.py, restatement-only): well-formed, marked, its titin
+    entry is the md5 the GPU test uses, and the entries a CPU run can afford are RE-DERIVED here with the oracle: the
+    score of the synthetic 2^16 pair (striped oracle, seconds) and score, length and column md5 of one bench slot of
+    another size.  The 2^18 / 2^20 scores are not recomputed (minutes to a quarter of an hour): the GPU tests that
+    consume them are 'parity unpinned' beyond the p-independence and banded cross-checks they make themselves."""
     import json
     g = json.load(open(os.path.join(golden_dir, "oracle_only.json")))
     assert "restatement" in g["produced_by"]
     t = [e for e in g["titin"] if e["b"] == "titin_mus.fasta" and e["a"].startswith("titin_homo")][0]
     assert (t["score"], t["alignment_len"], t["stdout_md5"]) == (62103, 35289, "65af487c90fa2638ce05f3a6badbaaea")
     from make_golden_shim import synth_protein
-    e16 = [e for e in g["synthetic"] if e["log2"] == 14 or e["log2"] == 16]
-    assert e16, "no synthetic entries"
-    k = 12   # a size this test can afford every run; the committed 2^16 .. 2^20 scores come from the generator
+    threads = min(8, os.cpu_count() or 1)
+    e16 = [e for e in g["synthetic"] if e["log2"] == 16][0]
+    a = np.frombuffer(synth_protein(0xA0000000 + 16, 1 << 16).encode(), np.uint8)
+    b = np.frombuffer(synth_protein(0xB0000000 + 16, 1 << 16).encode(), np.uint8)
+    assert O.score(a, b, threads) == e16["score"] == 12738
+    slot0 = [e for e in g["bench_pairs"] if (e["slot"], e["n"], e["m"]) == (0, 1 << 16, 1 << 16)][0]
+    assert slot0["score"] == e16["score"]
+    e = [e for e in g["bench_pairs"] if (e["slot"], e["n"], e["m"]) == (2, 1 << 16, 40000)][0]
+    a = np.frombuffer(synth_protein(0xA0000000 + 16 + 0x200, 1 << 16).encode(), np.uint8)
+    b = np.frombuffer(synth_protein(0xB0000000 + 16 + 0x200, 1 << 16).encode(), np.uint8)[:40000]
+    sc, ai, bj = O.align(a, b, threads)
+    assert (int(sc), len(ai), hashlib.md5(ai.astype(np.int32).tobytes() + bj.astype(np.int32).tobytes()).hexdigest()) == \
+        (e["score"], e["alignment_len"], e["columns_md5"])
+    k = 12   # the striped oracle against the single-thread one
     a = synth_protein(0xA0000000 + k, 1 << k).encode()
     b = synth_protein(0xB0000000 + k, 1 << k).encode()
     assert O.score(a, b, 4) == O.score(a, b)
