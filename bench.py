@@ -380,7 +380,20 @@ def single_gpu(args):
         watchdog.start()
         stripes_info = stripes_figures(args, dist, backend, local)
         watchdog.cancel()
+    multi_leg = dist is not None and not args.no_stripes and torch.cuda.device_count() >= world and \
+        os.environ.get("PSA_BENCH_ONE_PROCESS_STRIPES", "1") != "0"
+    store = None
+    if multi_leg:
+        try:   # (the other ranks wait for rank 0's one-process leg on the rendezvous store: on the CPU, their GPUs idle)
+            store = torch.distributed.distributed_c10d._get_default_store()
+        except Exception:
+            multi_leg = False
     if rank != 0:
+        if multi_leg:
+            try:
+                store.wait(["psa_one_process_leg_done"], __import__("datetime").timedelta(seconds=240))
+            except Exception as e:
+                print("bench: rank %d stopped waiting for rank 0's one-process leg (%s)" % (rank, e), file=sys.stderr)
         try:
             dist.barrier()                # rank 0 is still measuring; leave together
             dist.destroy_process_group()
@@ -414,6 +427,11 @@ def single_gpu(args):
         out["stripes"] = stripes_info
         if "error" in stripes_info:
             out["stripes_failed"] = True
+    if multi_leg:
+        try:
+            out["stripes_one_process"] = stripes_one_process(psa_amd, world, k, gold.get(0, (None,))[0])
+        finally:
+            store.set("psa_one_process_leg_done", "1")
     extra = {}
     if not args.no_extra:
         stream = torch.cuda.current_stream().cuda_stream
@@ -535,6 +553,48 @@ def titin_figures(psa_amd, torch, np):
                                 "structural_ceiling": min(1.0, cells / ((tn + tm) * 65536.0))},
             "gcups_end_to_end_host_buffers": cells / dtt / 1e9, "ms_end_to_end_host_buffers": dtt * 1e3,
             "note": "host-buffer figure: psa_align incl. H2D, table build, D2H and prefix fix-up (stripe objects reused)"}
+
+
+def stripes_one_process(psa_amd, ngpu, log2n, gold_score):
+    """Strong scaling of ONE pair through the C ABI's own multi-GPU call (psa_align_multi / psa_score_multi): ONE
+    process -- this rank -- drives `ngpu` GPUs, stripe g on GPU g, boundaries written GPU to GPU through peer-mapped
+    fine-grained memory (no collective library, no launcher).  2^k x 2^k full alignment and 2^20 x 2^20 score only."""
+    info = {"gpus": ngpu, "route": "psa_align_multi / psa_score_multi from rank 0 (one process, peer access over xGMI)"}
+    try:
+        k = log2n
+        n = m = 1 << k
+        a = psa_amd.synth_protein(0xA0000000 + k, n)
+        b = psa_amd.synth_protein(0xB0000000 + k, m)
+        best, fills, res = None, [], None
+        for rep in range(3):
+            t0 = time.perf_counter()
+            res = psa_amd.align_multi(a, b, ngpu=ngpu)
+            dt = time.perf_counter() - t0
+            fills.append(psa_amd.multi_last_fill_ms())
+            best = dt if best is None else min(best, dt)
+        assert gold_score is None or res.score == gold_score, (res.score, gold_score)
+        fill = min(fills[1:])
+        info["2p%d_full_alignment" % k] = {
+            "fill_ms": fill, "gcups_fill": float(n) * m / (fill * 1e-3) / 1e9, "score": int(res.score), "alignment_len": int(len(res.ai)),
+            "call_ms": best * 1e3, "call_note": "the whole call: buffers allocated, sequences uploaded, fill, walk across the GPUs, freed",
+            "valu_frac_of_all_gpus": float(n) * m * OPS_PER_CELL_CODES / (fill * 1e-3) / 1e12 / (VALU_PEAK_TOPS * ngpu),
+            "structural_ceiling": min(1.0, float(n) * m / ((n + m) * 65536.0 * ngpu)), "scaling": "strong"}
+        k = int(os.environ.get("PSA_BENCH_STRIPES_LOG2N", "20"))
+        n = m = 1 << k
+        a = psa_amd.synth_protein(0xA0000000 + k, n)
+        b = psa_amd.synth_protein(0xB0000000 + k, m)
+        fills = []
+        for rep in range(2):
+            sc = psa_amd.score_multi(a, b, ngpu=ngpu)
+            fills.append(psa_amd.multi_last_fill_ms())
+        fill = min(fills)
+        info["2p%d_score_only" % k] = {
+            "fill_ms": fill, "gcups_fill": float(n) * m / (fill * 1e-3) / 1e9, "score": int(sc),
+            "valu_frac_of_all_gpus": float(n) * m * OPS_PER_CELL_SCORE / (fill * 1e-3) / 1e12 / (VALU_PEAK_TOPS * ngpu),
+            "structural_ceiling": min(1.0, float(n) * m / ((n + m) * 65536.0 * ngpu)), "scaling": "strong"}
+    except Exception as e:   # (a secondary leg: its failure is reported, the line stands)
+        info["error"] = "%s: %s" % (type(e).__name__, e)
+    return info
 
 
 def stripes_figures(args, dist, backend, local):

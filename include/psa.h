@@ -72,6 +72,28 @@ int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
 /* Free the device buffers psa_align / psa_score keep for the calling thread (see psa_align). */
 void psa_release_cache(void);
 
+/*
+ * run() with its p workers on several GPUs of THIS process (simple.cpp:261-277 spawns its workers inside run(), so
+ * the reference's caller gets the parallel run from the one call; this is that call for GPUs).  B is cut into ngpu
+ * column stripes exactly as simple.cpp:90-99 cuts it for p = ngpu; stripe g is filled by ONE launch on GPU
+ * devices[g] (NULL: GPU g modulo the number of visible GPUs).  The boundary between stripes g and g+1 -- T1,T2,T3 of stripe g's last
+ * column per row and one "done" flag per 64 rows, the mailbox of simple.cpp:136-154 / 215-235 -- is fine-grained
+ * memory of GPU g+1 that GPU g's fill writes directly (peer access over xGMI) and GPU g+1's fill polls: no
+ * collective library, no launcher, no host loop while the fills run.  The walk goes right to left through the
+ * stripes, each on its own GPU.  Result = psa_align's for any ngpu.  A device may be named more than once if the
+ * stripes that share it fit on it together (ceil(n / 256) workgroups each, one per compute unit); ngpu = 1, or
+ * an alphabet of more than 32 symbols, is psa_align(p = ngpu) on the current GPU.  Needs hipDeviceCanAccessPeer
+ * between neighbours.  psa_score_multi: the same without traceback storage (BASELINE config 4, 2^20 x 2^20).
+ * The `./simple` front end calls psa_align_multi when PSA_GPUS=N (N > 1) is set in the environment.
+ */
+int psa_align_multi(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const int* devices, int ngpu,
+                    int32_t* score_out, int32_t** ai_out, int32_t** bj_out, int64_t* len_out);
+int psa_score_multi(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const int* devices, int ngpu,
+                    int32_t* score_out, int32_t triple_out[3]);
+/* Milliseconds (host clock) from the first stripe's fill being queued to every stripe's fill being complete, in the
+ * calling thread's most recent psa_align_multi / psa_score_multi: the fill pipeline without allocation, upload and walk. */
+double psa_multi_last_fill_ms(void);
+
 /* ---- several pairs at once: run() called in a loop (simple.cpp:311), one launch per batch ------
  *
  * One 2^16 pair cannot fill the GPU (its dependency chain is n + m anti-diagonal steps long whatever

@@ -16,12 +16,14 @@ from .binding import (  # noqa: F401
     Stripe,
     align,
     align_many,
+    align_multi,
     device_count,
     edge_post,
     finish_alignment,
     format_result,
     lib,
     lib_path,
+    multi_last_fill_ms,
     pick,
     read_fasta,
     read_fasta_records,
@@ -29,6 +31,7 @@ from .binding import (  # noqa: F401
     run,
     score,
     score_batch,
+    score_multi,
     stream_create,
     stream_destroy,
     set_device,

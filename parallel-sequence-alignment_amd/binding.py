@@ -36,6 +36,10 @@ _SIGNATURES = {
                             C.POINTER(C.c_void_p), _i64p]),
     "psa_align_banded": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, _i64, _i32p, C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), _i64p]),
+    "psa_align_multi": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, C.POINTER(C.c_int), C.c_int, _i32p,
+                                  C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _i64p]),
+    "psa_score_multi": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, C.POINTER(C.c_int), C.c_int, _i32p, _i32p]),
+    "psa_multi_last_fill_ms": (C.c_double, []),
     "psa_score": (C.c_int, [C.c_void_p, _i64, C.c_void_p, _i64, C.c_int, _i32p, _i32p]),
     "psa_score_batch": (C.c_int, [C.c_void_p, C.c_void_p, _i64, C.c_void_p, _i64, C.c_void_p]),
     "psa_score_batch_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_int, C.c_void_p, C.c_void_p,
@@ -171,6 +175,43 @@ def align(a, b, p=1, band_rows=None):
 
 
 run = lambda p, a, b: align(a, b, p)  # noqa: E731  (argument order of the reference)
+
+
+def _devices(devices, ngpu):
+    if devices is None:
+        return None, int(ngpu)
+    arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+    return arr, len(devices)
+
+
+def align_multi(a, b, ngpu=None, devices=None):
+    """run(p, A, B) with its p = ngpu workers on several GPUs of this process (psa_align_multi): stripe g on
+    devices[g] (default: GPUs 0 .. ngpu-1)."""
+    a, b = _seq(a), _seq(b)
+    dev, ng = _devices(devices, ngpu)
+    score = _i32()
+    ai, bj, n = C.c_void_p(), C.c_void_p(), _i64()
+    _check(lib().psa_align_multi(_ptr(a), a.size, _ptr(b), b.size, dev, ng, C.byref(score), C.byref(ai), C.byref(bj), C.byref(n)))
+    try:
+        xa = np.ctypeslib.as_array(C.cast(ai, _i32p), shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
+        xb = np.ctypeslib.as_array(C.cast(bj, _i32p), shape=(n.value,)).copy() if n.value else np.zeros(0, np.int32)
+    finally:
+        lib().psa_free(ai)
+        lib().psa_free(bj)
+    return Result(score.value, xa, xb)
+
+
+def multi_last_fill_ms():
+    return lib().psa_multi_last_fill_ms()
+
+
+def score_multi(a, b, ngpu=None, devices=None, triple=False):
+    a, b = _seq(a), _seq(b)
+    dev, ng = _devices(devices, ngpu)
+    s = _i32()
+    t = (_i32 * 3)()
+    _check(lib().psa_score_multi(_ptr(a), a.size, _ptr(b), b.size, dev, ng, C.byref(s), t))
+    return (s.value, tuple(t)) if triple else s.value
 
 
 def score(a, b, p=1, triple=False):

@@ -48,18 +48,18 @@ __global__ void build_eqtab(const uint8_t* b, int W, const unsigned* meta, const
 
 // ---- boundary chunks of a flagged fill (psa_stripe_fill_flagged: one launch over all rows of a stripe whose left
 // boundary arrives, and whose right boundary leaves, in row chunks while the launch runs) ----
-// packed[k][y] (k < 3, y < rows) -> plane[k * n + r0 + y].  Stored past this CU's cache: the fill reads them with
-// device-scope loads once it has seen the flags, which edge_flags raises in a launch of its own behind this one.
+// packed[k][y] (k < 3, y < rows) -> plane[k * n + r0 + y].  Stored past this GPU's caches (system scope, as the fill's
+// own boundary accesses: kEdgeScope in psa_fill_v2.hip.h): the fill reads them with loads of the same scope once it has seen the flags, which edge_flags raises in a launch of its own behind this one.
 __global__ void edge_scatter(const int32_t* packed, int64_t r0, int64_t rows, int64_t n, int32_t* plane) {
     const int64_t total = 3 * rows, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int64_t k = e / rows, y = e - k * rows;
-        __hip_atomic_store(plane + k * n + r0 + y, packed[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(plane + k * n + r0 + y, packed[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 __global__ void edge_flags(uint32_t* flags, unsigned count) {
     const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < count) __hip_atomic_store(flags + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e < count) __hip_atomic_store(flags + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // Waits until the fill has raised the flag of EVERY strip of the chunk, then plane[k * n + r0 + y] -> packed[k][y].
 // (Strips do not raise their flags in order: a strip with a right boundary raises its flag only after its second,
@@ -73,10 +73,10 @@ __global__ void edge_gather(const int32_t* plane, const uint32_t* done, int64_t 
     const unsigned long long t0 = wall_clock64();
     int good = 1;
     for (int64_t f = f0 + threadIdx.x; f <= f1 && good; f += blockDim.x) {
-        while (__hip_atomic_load(done + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        while (__hip_atomic_load(done + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
             __builtin_amdgcn_s_sleep(127);
-            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > 2 * kSpinTicks) {
-                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) || wall_clock64() - t0 > 2 * kSpinTicks) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 good = 0;
                 break;
             }
@@ -86,7 +86,7 @@ __global__ void edge_gather(const int32_t* plane, const uint32_t* done, int64_t 
     const int64_t total = 3 * rows, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
         const int64_t k = e / rows, y = e - k * rows;
-        packed[e] = __hip_atomic_load(plane + k * n + r0 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        packed[e] = __hip_atomic_load(plane + k * n + r0 + y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

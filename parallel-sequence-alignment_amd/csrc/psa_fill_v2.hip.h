@@ -143,6 +143,13 @@ __device__ __forceinline__ void lds_post(int* p, int v) {
     PSA_COMPILER_BARRIER();
 }
 
+// Scope of the loads and stores that carry a stripe's boundary (values and "done" flags) to the stripe beside it.
+// The neighbour may be filled by another launch on ANOTHER GPU of the same process (psa_align_multi: the buffers
+// are fine-grained memory of the consumer's GPU, written over xGMI), so these few accesses per strip are
+// system-scope: write-through stores, s_waitcnt vmcnt(0), then the flag; the consumer polls the flag and reads
+// past its caches.  On one GPU the cost is nil (a dozen accesses per strip of 64 rows).
+constexpr int kEdgeScope = __HIP_MEMORY_SCOPE_SYSTEM;
+
 // Bounded waiting.  The bound is wall-clock time (s_memrealtime, 100 MHz), not an iteration count:
 // with several kernels or processes sharing the GPU a wait can be long in iterations without
 // anything being wrong.  Looked at once per 1024 polls, together with the abort flag (rarely:
@@ -590,19 +597,19 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
             // (and the row above them), then read them past this CU's cache (agent scope), as it stored them
             Spin spins;
             for (;;) {
-                const unsigned f1 = __hip_atomic_load(p.left_done + sg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned f0 = sg > 0 ? __hip_atomic_load(p.left_done + sg - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+                const unsigned f1 = __hip_atomic_load(p.left_done + sg, __ATOMIC_RELAXED, kEdgeScope);
+                const unsigned f0 = sg > 0 ? __hip_atomic_load(p.left_done + sg - 1, __ATOMIC_RELAXED, kEdgeScope) : 1u;
                 if (__builtin_amdgcn_readfirstlane(f1 & f0)) break;
                 if (spin_expired(spins, p.abort_flag)) return;
                 __builtin_amdgcn_s_sleep(32);
             }
-            o1 = __hip_atomic_load(p.left + yo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            o2 = __hip_atomic_load(p.left + R + yo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            o3 = __hip_atomic_load(p.left + 2 * R + yo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            o1 = __hip_atomic_load(p.left + yo, __ATOMIC_RELAXED, kEdgeScope);
+            o2 = __hip_atomic_load(p.left + R + yo, __ATOMIC_RELAXED, kEdgeScope);
+            o3 = __hip_atomic_load(p.left + 2 * R + yo, __ATOMIC_RELAXED, kEdgeScope);
             if (yo >= 1) {
-                u1 = __hip_atomic_load(p.left + yo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u2 = __hip_atomic_load(p.left + R + yo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                u3 = __hip_atomic_load(p.left + 2 * R + yo - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u1 = __hip_atomic_load(p.left + yo - 1, __ATOMIC_RELAXED, kEdgeScope);
+                u2 = __hip_atomic_load(p.left + R + yo - 1, __ATOMIC_RELAXED, kEdgeScope);
+                u3 = __hip_atomic_load(p.left + 2 * R + yo - 1, __ATOMIC_RELAXED, kEdgeScope);
             } else boundary_triple(0, c0, u1, u2, u3);   // (one launch covers all rows: r0 == 0)
         } else {
             o1 = p.left[yo]; o2 = p.left[R + yo]; o3 = p.left[2 * R + yo];
@@ -724,9 +731,9 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         if (row_ok) {
             const int bias = (int)(3 * (i + c0 + W));
             if (p.right && p.right_done) {   // read by the next stripe inside this launch: write through
-                __hip_atomic_store(p.right + c.y_row, c.S.r1 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.right + R + c.y_row, c.S.r2 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.right + 2 * R + c.y_row, c.S.r3 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.right + c.y_row, c.S.r1 - bias, __ATOMIC_RELAXED, kEdgeScope);
+                __hip_atomic_store(p.right + R + c.y_row, c.S.r2 - bias, __ATOMIC_RELAXED, kEdgeScope);
+                __hip_atomic_store(p.right + 2 * R + c.y_row, c.S.r3 - bias, __ATOMIC_RELAXED, kEdgeScope);
             } else if (p.right) {
                 p.right[c.y_row] = c.S.r1 - bias; p.right[R + c.y_row] = c.S.r2 - bias; p.right[2 * R + c.y_row] = c.S.r3 - bias;
             }
@@ -736,7 +743,7 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         }
         if (p.right_done) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left before the flag does
-            if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, kEdgeScope);
         }
     }
 #ifdef PSA_FILL_STATS
@@ -770,9 +777,9 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         if (row_ok) {
             const int bias = (int)(3 * (i + c0 + W));
             if (p.right && p.right_done) {   // read by the next stripe inside this launch: write through
-                __hip_atomic_store(p.right + c.y_row, c.S.r1 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.right + R + c.y_row, c.S.r2 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.right + 2 * R + c.y_row, c.S.r3 - bias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(p.right + c.y_row, c.S.r1 - bias, __ATOMIC_RELAXED, kEdgeScope);
+                __hip_atomic_store(p.right + R + c.y_row, c.S.r2 - bias, __ATOMIC_RELAXED, kEdgeScope);
+                __hip_atomic_store(p.right + 2 * R + c.y_row, c.S.r3 - bias, __ATOMIC_RELAXED, kEdgeScope);
             } else if (p.right) {
                 p.right[c.y_row] = c.S.r1 - bias; p.right[R + c.y_row] = c.S.r2 - bias; p.right[2 * R + c.y_row] = c.S.r3 - bias;
             }
@@ -782,7 +789,7 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
         }
         if (p.right_done) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left before the flag does
-            if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(p.right_done + sg, 1u, __ATOMIC_RELAXED, kEdgeScope);
         }
     }
 }

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -961,6 +962,201 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
         to.codes_base = base; to.W = Wr; to.row_min = r0;
         rc = traceback_impl(s, &i, &j, &k, ai, bj, cap, &len, nullptr, to);
     }
+    if (rc == PSA_OK) rc = psa_finish_alignment(ai, bj, len, cap, &len);
+    if (rc != PSA_OK) { free(ai); free(bj); return rc; }
+    *score_out = v;
+    *ai_out = ai; *bj_out = bj; *len_out = len;
+    return PSA_OK;
+}
+
+}  // extern "C"
+
+
+// ---- run() with its p workers on several GPUs of ONE process (psa_align_multi / psa_score_multi) ----
+// simple.cpp:261-277 spawns its workers inside run(): the caller of the drop-in boundary gets the parallel run without
+// a launcher, a process group or a collective library.  Here: stripe g of B (simple.cpp:90-99) lives on GPU
+// devices[g] and is ONE flagged fill launch on a stream of that GPU; the boundary between stripes g and g+1 --
+// int32[3][n] and one flag per strip, the mailbox of simple.cpp:136-154 / 215-235 -- is fine-grained memory of GPU
+// g+1 that GPU g's fill writes directly over xGMI (peer access; system-scope write-through stores, s_waitcnt
+// vmcnt(0), then the flag) and GPU g+1's fill polls locally.  No post / take kernels, no host loop over chunks, no
+// dependence on how streams map to hardware queues: every launch only ever waits for a launch on ANOTHER GPU that
+// was started before it (or, for stripes that share a GPU, for workgroups that are resident beside its own).
+namespace {
+
+thread_local double g_multi_fill_ms = 0.0;   // host clock: first fill queued -> every stripe's fill complete
+
+struct MultiRun {
+    std::vector<psa_stripe*> st;
+    std::vector<int> dev;
+    std::vector<hipStream_t> stream;
+    std::vector<int32_t*> edge;     // boundary g -> g+1 on dev[g+1]
+    std::vector<uint32_t*> flags;
+    int caller_dev = 0;
+    ~MultiRun() {
+        for (size_t g = 0; g < stream.size(); ++g) {
+            if (!stream[g]) continue;
+            hipSetDevice(dev[g]);
+            hipStreamSynchronize(stream[g]);
+            hipStreamDestroy(stream[g]);
+        }
+        for (auto* s : st) free_stripe(s);
+        for (size_t g = 0; g < edge.size(); ++g) {
+            hipSetDevice(dev[g + 1]);
+            hipFree(edge[g]);
+            if (g < flags.size()) hipFree(flags[g]);
+        }
+        hipSetDevice(caller_dev);
+    }
+};
+
+// Fills every stripe; t = T1,T2,T3 at (n, m).  PSA_E_STATE (nothing launched) when a stripe needs the generic kernel.
+int multi_fill(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const int* devices, int ngpu, uint32_t flags,
+               MultiRun& R, int32_t t[3]) {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    HIP_TRY(hipGetDevice(&R.caller_dev));
+    std::vector<std::pair<int64_t, int64_t>> cols;
+    const int64_t block = m / ngpu;   // simple.cpp:90-99; zero-width stripes (ngpu > m) own no cell
+    for (int id = 0; id < ngpu; ++id) {
+        const int64_t c0 = (int64_t)id * block, c1 = (id == ngpu - 1) ? m : c0 + block;
+        if (c1 == c0) continue;
+        const int d = devices ? devices[id] : id % ndev;   // (no list: round the visible GPUs; sharing is checked below)
+        if (d < 0 || d >= ndev) return fail(PSA_E_ARG, "psa_align_multi: stripe %d names device %d, %d device(s) visible", id, d, ndev);
+        cols.push_back({c0, c1});
+        R.dev.push_back(d);
+    }
+    const size_t G = cols.size();
+    // Stripes that share a GPU are separate launches whose waiting strips hold their CUs: all of them must be
+    // resident together (one workgroup of 256 rows per CU).  One GPU for everything is psa_align(p)'s case: there the
+    // stripes are jobs of ONE launch and any size goes.
+    const int64_t groups = ((n + 63) / 64 + psa::kNW - 1) / psa::kNW;
+    for (size_t g = 0; g < G; ++g) {
+        int64_t sharing = 0;
+        for (size_t h = 0; h < G; ++h) sharing += R.dev[h] == R.dev[g];
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, R.dev[g]));
+        if (sharing > 1 && sharing * groups > cus)
+            return fail(PSA_E_ARG, "psa_align_multi: %lld stripes of %lld rows share device %d and do not fit on it together "
+                        "(%lld workgroups each, %d compute units): give every stripe a GPU of its own, or use psa_align(p)",
+                        (long long)sharing, (long long)n, R.dev[g], (long long)groups, cus);
+    }
+    const size_t strips = (size_t)((n + 63) / 64);
+    for (size_t g = 0; g < G; ++g) {
+        HIP_TRY(hipSetDevice(R.dev[g]));
+        hipStream_t st = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        R.stream.push_back(st);
+        psa_stripe* s = nullptr;
+        int rc = alloc_stripe(&s, n, (int)(cols[g].second - cols[g].first), flags, cols[g].first > 0);
+        if (rc == PSA_OK) R.st.push_back(s);
+        if (rc == PSA_OK) rc = bind_stripe(s, n, m, cols[g].first, cols[g].second);
+        if (rc == PSA_OK) rc = upload_host(s, a, b, st);
+        if (rc != PSA_OK) return rc;
+        if (!s->use_v2) return fail(PSA_E_STATE, "psa_align_multi: alphabet of more than %d symbols (generic kernel)", psa::kMaxSym);
+        if (g + 1 < G) {
+            if (R.dev[g] != R.dev[g + 1]) {
+                int can = 0;
+                HIP_TRY(hipDeviceCanAccessPeer(&can, R.dev[g], R.dev[g + 1]));
+                if (!can) return fail(PSA_E_HIP, "psa_align_multi: device %d cannot access the memory of device %d", R.dev[g], R.dev[g + 1]);
+                const hipError_t e = hipDeviceEnablePeerAccess(R.dev[g + 1], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(PSA_E_HIP, "hipDeviceEnablePeerAccess(%d) from device %d failed: %s", R.dev[g + 1], R.dev[g], hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+            HIP_TRY(hipSetDevice(R.dev[g + 1]));   // the boundary lives with its consumer: polled locally, written remotely
+            int32_t* e = nullptr;
+            uint32_t* f = nullptr;
+            HIP_TRY(hipExtMallocWithFlags((void**)&e, sizeof(int32_t) * 3 * (size_t)n, hipDeviceMallocFinegrained));
+            R.edge.push_back(e);
+            HIP_TRY(hipExtMallocWithFlags((void**)&f, sizeof(uint32_t) * (strips + 64), hipDeviceMallocFinegrained));
+            R.flags.push_back(f);
+            HIP_TRY(hipMemset(f, 0, sizeof(uint32_t) * (strips + 64)));
+            HIP_TRY(hipDeviceSynchronize());
+        }
+    }
+    for (size_t g = 0; g < G; ++g) {   // sequences and tables in place before any fill is queued
+        HIP_TRY(hipSetDevice(R.dev[g]));
+        HIP_TRY(hipStreamSynchronize(R.stream[g]));
+    }
+    const auto t_begin = std::chrono::steady_clock::now();
+    for (size_t g = 0; g < G; ++g) {   // head stripe first: a launch only ever waits for launches queued before it
+        FillOpts o;
+        o.left_done = g ? R.flags[g - 1] : nullptr;
+        o.right_done = (g + 1 < G) ? R.flags[g] : nullptr;
+        if (int rc = fill_rows_impl(R.st[g], 0, n, g ? R.edge[g - 1] : nullptr, (g + 1 < G) ? R.edge[g] : nullptr, R.stream[g], o)) return rc;
+    }
+    for (size_t g = 0; g < G; ++g) {
+        HIP_TRY(hipSetDevice(R.dev[g]));
+        HIP_TRY(hipStreamSynchronize(R.stream[g]));
+    }
+    g_multi_fill_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    for (size_t g = 0; g + 1 < G; ++g) {
+        DeviceGuard dg(R.dev[g]);
+        if (dg.rc) return dg.rc;
+        if (int rc = check_abort(R.st[g], R.stream[g])) return rc;
+    }
+    return psa_stripe_final(R.st.back(), R.stream.back(), t);
+}
+
+int multi_args_ok(const char* who, int64_t n, const uint8_t* a, int64_t m, const uint8_t* b, int ngpu) {
+    if (n < 0 || m < 0 || (n && !a) || (m && !b)) return fail(PSA_E_ARG, "%s: bad argument", who);
+    if (ngpu < 1) return fail(PSA_E_ARG, "%s: ngpu must be >= 1 (the reference divides by p, simple.cpp:92)", who);
+    if (n > (1LL << 27) || m > (1LL << 27)) return fail(PSA_E_ARG, "sequence longer than 2^27 is not supported");
+    return need_device();
+}
+
+}  // namespace
+
+extern "C" {
+
+double psa_multi_last_fill_ms(void) { return g_multi_fill_ms; }
+
+int psa_score_multi(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const int* devices, int ngpu,
+                    int32_t* score_out, int32_t triple_out[3]) {
+    if (!score_out) return fail(PSA_E_ARG, "psa_score_multi: bad argument");
+    if (int rc = multi_args_ok("psa_score_multi", n, a, m, b, ngpu)) return rc;
+    if (n == 0 || m == 0) return psa_score(a, n, b, m, 1, score_out, triple_out);
+    int32_t t[3];
+    int rc;
+    {
+        MultiRun R;
+        rc = multi_fill(a, n, b, m, devices, ngpu, 0, R, t);
+    }
+    if (rc == PSA_E_STATE) return psa_score(a, n, b, m, ngpu, score_out, triple_out);   // generic kernel: this GPU only
+    if (rc != PSA_OK) return rc;
+    pick3(t, score_out);
+    if (triple_out) memcpy(triple_out, t, sizeof t);
+    return PSA_OK;
+}
+
+int psa_align_multi(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const int* devices, int ngpu,
+                    int32_t* score_out, int32_t** ai_out, int32_t** bj_out, int64_t* len_out) {
+    if (!score_out || !ai_out || !bj_out || !len_out) return fail(PSA_E_ARG, "psa_align_multi: bad argument");
+    if (int rc = multi_args_ok("psa_align_multi", n, a, m, b, ngpu)) return rc;
+    if (n == 0 || m == 0) return psa_align(a, n, b, m, 1, score_out, ai_out, bj_out, len_out);
+    *ai_out = *bj_out = nullptr;
+    *len_out = 0;
+    const int64_t cap = 2 * (n + m) + 2;
+    int32_t* ai = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+    int32_t* bj = (int32_t*)malloc(sizeof(int32_t) * (size_t)cap);
+    if (!ai || !bj) { free(ai); free(bj); return fail(PSA_E_NOMEM, "psa_align_multi: host allocation failed"); }
+    int32_t t[3], v = 0;
+    int64_t len = 0;
+    int rc;
+    {
+        MultiRun R;
+        rc = multi_fill(a, n, b, m, devices, ngpu, PSA_F_TRACEBACK, R, t);
+        if (rc == PSA_OK) {
+            // the walk: right to left through the stripes, each on its own GPU, (i, j, k) handed on (psa.h)
+            int64_t i = n, j = m;
+            int k = pick3(t, &v);
+            for (size_t g = R.st.size(); g-- > 0 && rc == PSA_OK;) {
+                rc = psa_stripe_traceback(R.st[g], &i, &j, &k, ai, bj, cap, &len, R.stream[g]);
+                if (i == 0 || j == 0) break;
+            }
+        }
+    }
+    if (rc == PSA_E_STATE) { free(ai); free(bj); return psa_align(a, n, b, m, ngpu, score_out, ai_out, bj_out, len_out); }
     if (rc == PSA_OK) rc = psa_finish_alignment(ai, bj, len, cap, &len);
     if (rc != PSA_OK) { free(ai); free(bj); return rc; }
     *score_out = v;

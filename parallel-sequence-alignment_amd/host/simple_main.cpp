@@ -30,7 +30,12 @@ int main(int argc, char* argv[]) {
     int32_t score = 0;
     int32_t *ai = nullptr, *bj = nullptr;
     int64_t len = 0;
-    const int rc = psa_align(a, n, b, m, p, &score, &ai, &bj, &len);
+    // PSA_GPUS=N (N > 1): run()'s workers on N GPUs of this process -- B cut into N column stripes, one per GPU
+    // (psa_align_multi); the output does not depend on it, as the reference's does not depend on p.
+    const char* gpus_env = std::getenv("PSA_GPUS");
+    const int gpus = gpus_env ? std::atoi(gpus_env) : 0;
+    const int rc = gpus > 1 ? psa_align_multi(a, n, b, m, nullptr, gpus, &score, &ai, &bj, &len)
+                            : psa_align(a, n, b, m, p, &score, &ai, &bj, &len);
     if (rc != PSA_OK) {
         std::cerr << "simple: " << psa_last_error() << " (code " << rc << ")\n";
         return 3;

@@ -655,3 +655,56 @@ def test_flagged_fill_boundaries_by_flags():
         psa_amd.edge_post(bufs[0].data_ptr(), 32, 64, n, left.data_ptr(), left_ready.data_ptr(), 0)
     s0.close(); s1.close()
     psa_amd.stream_destroy(f0); psa_amd.stream_destroy(f1)
+
+
+def test_align_multi_stripes_as_separate_launches(golden_dir):
+    """psa_align_multi / psa_score_multi (run() with its workers on several GPUs of one process, simple.cpp:261-277):
+    every stripe is a launch of its own on its own stream and the boundary travels through fine-grained memory and
+    per-strip flags that the neighbour's launch polls.  On the one GPU of the test box: ngpu = 2, 3 and 5 with every
+    stripe on device 0 (the launches are resident together), against the oracle column for column; sizes that leave
+    partial strips and narrow last stripes; the error paths."""
+    rng = np.random.default_rng(91)
+    for n, m, alpha in ((6000, 5000, 4), (700, 2211, 20), (130, 130, 2), (64, 7, 3), (5000, 9000, 20)):
+        a = rng.integers(65, 65 + alpha, n).astype(np.uint8)
+        b = np.where(rng.random(m) < 0.6, np.resize(a, m), rng.integers(65, 65 + alpha, m)).astype(np.uint8)
+        sc, ai, bj = O.align(a, b)
+        t1 = psa_amd.score(a, b, 1, triple=True)
+        for ng in (2, 3, 5):
+            res = psa_amd.align_multi(a, b, devices=[0] * ng)
+            assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (n, m, ng)
+            assert psa_amd.score_multi(a, b, devices=[0] * ng, triple=True) == t1, (n, m, ng)
+        res = psa_amd.align_multi(a, b, ngpu=2)      # no device list: stripe g on GPU g mod the visible GPUs
+        assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (n, m)
+    # the reference's FASTA pairs and degenerate inputs
+    a = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "Q16739_homo.fasta"))
+    b = psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "A0A2I3N2W7_baboon.fasta"))
+    gold = [c for c in O.load_golden("ref_fasta_pairs.json") if c["a"] == "Q16739_homo.fasta" and c["b"] == "A0A2I3N2W7_baboon.fasta"][0]
+    assert psa_amd.format_result(psa_amd.align_multi(a, b, devices=[0, 0, 0, 0]), a, b) == O.b64d(gold["stdout_b64"])
+    for x, y in ((b"", b"ACD"), (b"ACD", b""), (b"A", b"C"), (b"ACDEF", b"AC")):
+        res = psa_amd.align_multi(x, y, devices=[0, 0, 0])          # (ngpu > m: zero-width stripes own no cell)
+        sc, ai, bj = O.align(x, y)
+        assert (res.score, list(res.ai), list(res.bj)) == (sc, list(ai), list(bj)), (x, y)
+    # more than 32 symbols: the generic kernel, on the current GPU
+    a = rng.integers(40, 100, 777).astype(np.uint8)
+    b = rng.integers(40, 100, 555).astype(np.uint8)
+    sc, ai, bj = O.align(a, b)
+    res = psa_amd.align_multi(a, b, devices=[0, 0])
+    assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj)
+    # stripes that share a GPU and do not fit on it together; a device that does not exist; ngpu < 1
+    big = psa_amd.synth_protein(1, 1 << 16)
+    with pytest.raises(psa_amd.PsaError):
+        psa_amd.align_multi(big, big, devices=[0, 0])
+    with pytest.raises(psa_amd.PsaError):
+        psa_amd.align_multi(a, b, devices=[0, 99])
+    with pytest.raises(psa_amd.PsaError):
+        psa_amd.align_multi(a, b, ngpu=0)
+
+
+def test_cli_psa_gpus(golden_dir):
+    """PSA_GPUS=N ./simple A B p: the front end's route to psa_align_multi, byte-exact stdout."""
+    exe = os.path.join(ROOT, "simple")
+    env = dict(os.environ, PSA_GPUS="3")
+    for c in O.load_golden("ref_fasta_pairs.json")[:4]:
+        r = subprocess.run([exe, c["a"], c["b"], str(c["p"])], cwd=golden_dir, capture_output=True, timeout=120, env=env)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == O.b64d(c["stdout_b64"])
