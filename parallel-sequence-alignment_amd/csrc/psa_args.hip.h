@@ -113,11 +113,13 @@ struct BatchArgs {
     int32_t* scores;
     unsigned* next_pair;   // work counter, zeroed before the launch
     int max_b;             // longest second sequence in the batch, rounded up to a multiple of 64
+    int no_packed;         // 1: every pair through the int32 path (cross-check of the packed 16-bit path: PSA_BATCH_PACKED=0)
 };
 
 // dynamic LDS per wave: row buffer (slot s = (D of column s-65, V of column s-64), as in fill v2),
-// B bytes with 128 bytes of padding in front, and a dump for the lanes that publish nothing
+// B residues with 128 entries of padding in front, and a dump for the lanes that publish nothing
 __host__ __device__ inline int batch_row_slots(int max_b) { return max_b + 160; }
-__host__ __device__ inline int batch_wave_bytes(int max_b) { return batch_row_slots(max_b) * 8 + (max_b + 256) + 112 * 4; }
+// (the B region holds one int per column for a couple of pairs in the packed 16-bit path, bytes in the int32 path)
+__host__ __device__ inline int batch_wave_bytes(int max_b) { return batch_row_slots(max_b) * 8 + 4 * (max_b + 256) + 112 * 4; }
 
 }  // namespace psa

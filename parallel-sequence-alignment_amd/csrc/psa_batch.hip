@@ -1,6 +1,7 @@
 // psa_batch.hip -- translation unit: the many-pairs score kernel (BASELINE config 5) and its C ABI entry points
 // (psa_score_batch_dev, psa_score_batch_dev_noalloc; include/psa.h).
 #include <algorithm>
+#include <cstdlib>
 
 #include "psa_batch.hip.h"
 #include "psa_host.h"
@@ -23,12 +24,14 @@ int psa_score_batch_dev(const uint8_t* seqs_dev, const int64_t* offsets_dev, con
     psa::BatchArgs ba;
     ba.seqs = seqs_dev; ba.offsets = offsets_dev; ba.pairs = pairs_dev; ba.npairs = npairs; ba.scores = scores_dev;
     ba.next_pair = counter_dev;
+    static const int no_packed = [] { const char* v = getenv("PSA_BATCH_PACKED"); return (v && v[0] == '0') ? 1 : 0; }();
+    ba.no_packed = no_packed;
     ba.max_b = std::max(64, ((max_len_b + 63) / 64) * 64);
     const size_t lds_bytes = (size_t)psa::kBatchWaves * psa::batch_wave_bytes(ba.max_b);
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int64_t want = (npairs + psa::kBatchWaves - 1) / psa::kBatchWaves;
+    const int64_t want = ((npairs + 1) / 2 + psa::kBatchWaves - 1) / psa::kBatchWaves;   // (a wavefront draws couples of pairs)
     const unsigned grid = (unsigned)std::min<int64_t>(want, (int64_t)cus * 8);
     hipLaunchKernelGGL(psa::batch_score_kernel, dim3(grid), dim3(psa::kBatchWaves * 64), lds_bytes, st, ba);
     HIP_TRY(hipGetLastError());

@@ -350,6 +350,41 @@ def test_batch_scores_match_oracle():
         assert got[idx] == O.score(prot[i], prot[j])
 
 
+def test_batch_packed_couples_match_oracle():
+    """The batch kernel takes pairs in couples (2c, 2c + 1); a couple whose second sequences have the same length goes
+    through the packed 16-bit path (two pairs per lane: psa_batch.hip.h, batch_couple_pk), any other through the int32
+    path.  Couples that share a target of every length around the block and strip edges, first sequences of different
+    lengths (their last rows in different strips), small alphabets (ties), an odd pair at the end, couples too long for
+    16 bits, couples with an empty first sequence: every score against the oracle."""
+    rng = np.random.default_rng(2025)
+    targets = [1, 2, 15, 16, 17, 63, 64, 65, 95, 96, 97, 111, 112, 113, 127, 128, 129, 200, 511, 512, 513, 1000, 1024]
+    seqs, pairs = [], []
+    for x, nb in enumerate(targets):
+        alpha = [2, 4, 20][x % 3]
+        t = len(seqs)
+        seqs.append(rng.integers(65, 65 + alpha, nb).astype(np.uint8))
+        lens = [1, 64, 65, int(rng.integers(1, 700)), int(rng.integers(1, 700)), 128, 129, 3 * nb + 1]
+        for k, na in enumerate(lens):
+            q = len(seqs)
+            # (some queries are mutated copies of the target: long diagonal runs and real gaps)
+            src = np.resize(seqs[t], na) if k % 2 else rng.integers(65, 65 + alpha, na).astype(np.uint8)
+            seqs.append(np.where(rng.random(na) < 0.8, src, rng.integers(65, 65 + alpha, na)).astype(np.uint8))
+            pairs.append((q, t))
+    # equal-length targets that are different sequences, and the same pair twice in one couple
+    a512 = [psa_amd.synth_protein(0xC0000000 + k, 512) for k in range(6)]
+    base = len(seqs)
+    seqs += a512
+    pairs += [(base, base + 1), (base + 2, base + 3), (base + 4, base + 4), (base + 4, base + 4), (base + 5, base)]
+    # too long for the 16-bit halves (nA + nB > 6000), an empty first sequence in a couple, an odd pair at the end
+    big = len(seqs)
+    seqs += [rng.integers(65, 69, 5800).astype(np.uint8), rng.integers(65, 69, 600).astype(np.uint8), np.zeros(0, np.uint8)]
+    pairs += [(big, big + 1), (big, big + 1), (big + 2, big + 1), (big + 1, big + 1), (big + 1, base)]
+    assert len(pairs) % 2 == 1
+    got = psa_amd.score_batch(seqs, pairs)
+    for (i, j), g in zip(pairs, got):
+        assert g == O.score(seqs[i], seqs[j]), (len(seqs[i]), len(seqs[j]), int(g))
+
+
 def test_batch_oversize_second_sequences_among_short_pairs():
     """Pairs whose second sequence exceeds the batch kernel's LDS row buffer (1024) are skipped by the kernel and
     sent through psa_score; the ordinary pairs of the same launch must not be disturbed by them."""
