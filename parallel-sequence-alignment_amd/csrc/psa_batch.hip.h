@@ -172,9 +172,9 @@ __device__ __forceinline__ int pk_bits(pk16 v) { return __builtin_bit_cast(int, 
 __device__ __forceinline__ pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ pk16 pk_both(int v) { return pk_of((v & 0xffff) | (v << 16)); }
 
-struct BatchStripPk {
-    pk16 D0, D1, H, V;
-    pk16 fin1, fin2, fin3;
+struct BatchStripPk {   // (plain ints, two 16-bit halves each: a struct of short vectors does not leave the stack)
+    int D0, D1, H, V;
+    int fin1, fin2, fin3;
 };
 
 // One block of 16 steps for a couple.  row: packed slots (D of column-1, V of column) of the row above; bp: this
@@ -189,6 +189,7 @@ __device__ __forceinline__ void batch_block_pk(BatchStripPk& S, const int2* row,
     int bq[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) bq[k] = bp[k];
+    int hd[16], hv[16];   // lane 63's row as it goes: (D one step ago, V) per step
     const pk16 two = pk_both(2), eight = pk_both(8);
     // (the slot address in a VGPR for the whole block -- as a uniform value it is moved there at every write --, kept
     // a 32-bit LDS address: the barrier on the generic pointer would turn the writes into flat stores)
@@ -196,41 +197,51 @@ __device__ __forceinline__ void batch_block_pk(BatchStripPk& S, const int2* row,
     unsigned pa_off = (unsigned)(uintptr_t)(lds_int*)pa;
     asm volatile("" : "+v"(pa_off));
     lds_int* pl = (lds_int*)(uintptr_t)pa_off;
+    // (the state in locals, the two D registers named explicitly per even / odd step: selecting a member of S by the step's
+    // parity keeps the whole struct on the stack -- a scratch store and load per step)
+    int D0 = S.D0, D1 = S.D1, H = S.H, V = S.V, f1 = S.fin1, f2 = S.fin2, f3 = S.fin3;
+    typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
+#define PSA_PK_STEP(k, DDIAG, DOUT, DPREV)                                                                           \
+    {                                                                                                                \
+        const int t = t0 + (k);                                                                                      \
+        const upk16 d = __builtin_bit_cast(upk16, bq[k]) - __builtin_bit_cast(upk16, a2);                            \
+        const upk16 z = __builtin_elementwise_min(d, __builtin_bit_cast(upk16, two)); /* 0: match, 2: mismatch */     \
+        const pk16 f = eight - __builtin_bit_cast(pk16, z);                                                          \
+        const int preD = ((k) & 1) ? pre[(k) >> 1].z : pre[(k) >> 1].x;                                              \
+        const int preV = ((k) & 1) ? pre[(k) >> 1].w : pre[(k) >> 1].y;                                              \
+        const pk16 x1 = pk_of(shift_down1(preD, DDIAG)) + f;                                                         \
+        const pk16 x3 = pk_of(shift_down1(preV, V));                                                                 \
+        const pk16 x2 = pk_of(H);                                                                                    \
+        const pk16 M = pk_max(x1, x2);                                                                               \
+        const pk16 D = pk_max(M, x3);                                                                                \
+        const pk16 Vn = pk_max(M, x3 + two); /* = max(D, x3 + 2) */                                                  \
+        const pk16 Hn = pk_max(D, x2 + two);                                                                         \
+        bool act = true;                                                                                             \
+        if (MODE == kBHead) act = lane <= t;                                                                         \
+        if (MODE == kBGeneric) act = lane <= t && t - lane < nB;                                                     \
+        if (MODE == kBTailCap || MODE == kBGeneric) {                                                                \
+            if (t - lane == nB - 1) { f1 = pk_bits(x1); f2 = pk_bits(x2); f3 = pk_bits(x3); } /* every lane: the owner is chosen afterwards */ \
+        }                                                                                                            \
+        hd[k] = DPREV; /* D of this row one step (column) ago */                                                     \
+        if (act) { DOUT = pk_bits(D); H = pk_bits(Hn); V = pk_bits(Vn); }                                            \
+        hv[k] = V;                                                                                                   \
+    }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int t = t0 + k;
-        typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
-        const upk16 d = __builtin_bit_cast(upk16, bq[k]) - __builtin_bit_cast(upk16, a2);
-        const upk16 z = __builtin_elementwise_min(d, __builtin_bit_cast(upk16, two));   // 0: match, 2: mismatch
-        const pk16 f = eight - __builtin_bit_cast(pk16, z);
-        const int preD = (k & 1) ? pre[k >> 1].z : pre[k >> 1].x;
-        const int preV = (k & 1) ? pre[k >> 1].w : pre[k >> 1].y;
-        const pk16 x1 = pk_of(shift_down1(preD, pk_bits((k & 1) ? S.D1 : S.D0))) + f;
-        const pk16 x3 = pk_of(shift_down1(preV, pk_bits(S.V)));
-        const pk16 x2 = S.H;
-        const pk16 M = pk_max(x1, x2);
-        const pk16 D = pk_max(M, x3);
-        const pk16 Vn = pk_max(M, x3 + two);      // = max(D, x3 + 2)
-        const pk16 Hn = pk_max(D, x2 + two);
-        bool act = true;
-        if (MODE == kBHead) act = lane <= t;
-        if (MODE == kBGeneric) act = lane <= t && t - lane < nB;
-        if (MODE == kBTailCap || MODE == kBGeneric) {
-            if (t - lane == nB - 1) { S.fin1 = x1; S.fin2 = x2; S.fin3 = x3; }   // (every lane: the owner is chosen afterwards)
-        }
-        const pk16 Dprev = (k & 1) ? S.D0 : S.D1;   // D of this row one step (column) ago
-        if (act) {
-            if (k & 1) S.D1 = D; else S.D0 = D;
-            S.H = Hn;
-            S.V = Vn;
-        }
-        // lane 63's row: slot of its column c = t - 63 is t + 1 = (D of column c - 1, V of column c), one 8-byte write;
-        // only lane 63 writes (the other lanes have nobody to hand their row to)
-        if (publish) {
-            typedef int v2i __attribute__((ext_vector_type(2)));
-            typedef __attribute__((address_space(3))) v2i lds_v2i;
-            *(lds_v2i*)(pl + 2 * (k + 1)) = v2i{pk_bits(Dprev), pk_bits(S.V)};
-        }
+    for (int k2 = 0; k2 < 16; k2 += 2) {
+        PSA_PK_STEP(k2, D0, D0, D1)
+        PSA_PK_STEP(k2 + 1, D1, D1, D0)
+    }
+#undef PSA_PK_STEP
+    S.D0 = D0; S.D1 = D1; S.H = H; S.V = V; S.fin1 = f1; S.fin2 = f2; S.fin3 = f3;
+    // lane 63's row leaves once per block: slot of its column c = t - 63 is t + 1 = (D of column c - 1, V of column c).
+    // Only lane 63 writes (the other lanes have nobody to hand their row to), and the sixteen writes share ONE change
+    // of the execution mask (tools/pk_step.hip: per block 62, per step 63, unmasked writes of all lanes 67 cycles a
+    // step at four wavefronts per SIMD, where the arithmetic alone takes 55-60).
+    if (publish) {
+        typedef int v2i __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(3))) v2i lds_v2i;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) *(lds_v2i*)(pl + 2 * (k + 1)) = v2i{hd[k], hv[k]};
     }
 }
 
@@ -256,7 +267,7 @@ __device__ __forceinline__ void batch_couple_pk(const BatchArgs& p, const int64_
         row[64 + jj] = make_int2(pk_bits(pk_both(max3i(t1, t2, t3) + 3 * jj)), pk_bits(pk_both(max3i(v1, v2, v3 + 2) + 3 * (jj + 1))));
     }
     BatchStripPk S;
-    S.fin1 = S.fin2 = S.fin3 = pk_both(0);
+    S.fin1 = S.fin2 = S.fin3 = 0;
     const int nAmax = max(nAX, nAY);
     const int nstrips = (nAmax + 63) >> 6;
     const int nblocks = (nB + 63 + 15) >> 4;
@@ -272,9 +283,9 @@ __device__ __forceinline__ void batch_couple_pk(const BatchArgs& p, const int64_
         int o1, o2, o3;
         boundary_triple(i, 0, o1, o2, o3);
         const int bias_own = 3 * i;
-        S.D0 = S.D1 = pk_both(max3i(o1, o2, o3) + bias_own);
-        S.H = pk_both(max3i(o1, o2 + 2, o3) + bias_own);
-        S.V = pk_both(0);
+        S.D0 = S.D1 = pk_bits(pk_both(max3i(o1, o2, o3) + bias_own));
+        S.H = pk_bits(pk_both(max3i(o1, o2 + 2, o3) + bias_own));
+        S.V = 0;
         const bool publish = lane == 63 && s + 1 < nstrips;   // the last strip feeds nobody
         const bool cap = (s == sx) || (s == sy);
         const int* bp = bpk - lane;
@@ -294,13 +305,13 @@ __device__ __forceinline__ void batch_couple_pk(const BatchArgs& p, const int64_
         }
         if (s == sx) {
             const int l = (nAX - 1) & 63;
-            fx1 = (short)__builtin_amdgcn_readlane(pk_bits(S.fin1), l); fx2 = (short)__builtin_amdgcn_readlane(pk_bits(S.fin2), l);
-            fx3 = (short)__builtin_amdgcn_readlane(pk_bits(S.fin3), l);
+            fx1 = (short)__builtin_amdgcn_readlane(S.fin1, l); fx2 = (short)__builtin_amdgcn_readlane(S.fin2, l);
+            fx3 = (short)__builtin_amdgcn_readlane(S.fin3, l);
         }
         if (s == sy) {
             const int l = (nAY - 1) & 63;
-            fy1 = __builtin_amdgcn_readlane(pk_bits(S.fin1), l) >> 16; fy2 = __builtin_amdgcn_readlane(pk_bits(S.fin2), l) >> 16;
-            fy3 = __builtin_amdgcn_readlane(pk_bits(S.fin3), l) >> 16;
+            fy1 = __builtin_amdgcn_readlane(S.fin1, l) >> 16; fy2 = __builtin_amdgcn_readlane(S.fin2, l) >> 16;
+            fy3 = __builtin_amdgcn_readlane(S.fin3, l) >> 16;
         }
     }
     // final picks (simple.cpp:246-256)
@@ -324,7 +335,10 @@ __device__ __forceinline__ void batch_couple_pk(const BatchArgs& p, const int64_
 // length (and whose sizes keep every value below 2^15) goes through the packed path, any other couple through
 // the int32 path one pair after the other.  Callers that want the packed rate list pairs that share a target (or
 // have targets of one length) next to each other -- an all-vs-all block ordered by target does (BASELINE config 5).
-__global__ __launch_bounds__(kBatchWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void batch_score_kernel(BatchArgs p) {
+#ifndef PSA_BATCH_MIN_WAVES
+#define PSA_BATCH_MIN_WAVES 3
+#endif
+__global__ __launch_bounds__(kBatchWaves * 64) __attribute__((amdgpu_waves_per_eu(PSA_BATCH_MIN_WAVES, 8))) void batch_score_kernel(BatchArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

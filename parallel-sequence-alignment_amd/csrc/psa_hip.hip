@@ -111,6 +111,8 @@ struct psa_stripe {
     int64_t tb_cap = 0;
     int64_t* tb_state = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pass_ev = nullptr;   // recorded behind the memsets that open a pass (r0 == 0); chunks on other streams wait for it
+    hipStream_t pass_stream = nullptr;
     int64_t next_r0 = 0;
     int corner_cur = 0;
     unsigned launch_no = 0;
@@ -120,6 +122,11 @@ struct psa_stripe {
     uint32_t* eqtab = nullptr;
     unsigned nsym = 0;
     bool use_v2 = false;
+    // sequences bound from DEVICE memory: the number of distinct residues comes back asynchronously (pinned word + event)
+    // and is looked at when the next fill is queued (settle_tables), not when the pair is bound
+    unsigned* h_nsym = nullptr;
+    hipEvent_t tab_ev = nullptr;
+    bool nsym_pending = false;
     bool fill_timed = false, tb_timed = false;
     // banded (linear-space) mode: codes cover band_rows rows at a time, ckpt holds the hand-off ring as it
     // was before each band (see align_banded)
@@ -156,6 +163,9 @@ void free_stripe(psa_stripe* s) {
     hipFree(s->ckpt); hipFree(s->done);
     hipFree(s->small); hipFree(s->ctrl); hipFree(s->tb_ai); hipFree(s->tb_bj); hipFree(s->tb_state);
     for (auto& e : s->ev) if (e) hipEventDestroy(e);
+    if (s->pass_ev) hipEventDestroy(s->pass_ev);
+    if (s->tab_ev) hipEventDestroy(s->tab_ev);
+    hipHostFree(s->h_nsym);
     delete s;
 }
 
@@ -203,6 +213,9 @@ int alloc_stripe(psa_stripe** out, int64_t n_cap, int W_cap, uint32_t flags, boo
         CREATE_TRY(hipMalloc(&s->tb_state, sizeof(int64_t) * 16));
     }
     for (auto& e : s->ev) CREATE_TRY(hipEventCreate(&e));
+    CREATE_TRY(hipEventCreateWithFlags(&s->pass_ev, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&s->tab_ev, hipEventDisableTiming));
+    CREATE_TRY(hipHostMalloc(&s->h_nsym, 64));
     CREATE_TRY(hipMalloc(&s->a_ids, (size_t)n_cap + 64));
     CREATE_TRY(hipMalloc(&s->alpha, kAlphaBytes));
     CREATE_TRY(hipMalloc(&s->eqtab, sizeof(uint32_t) * (size_t)psa::kMaxSym * (size_t)s->pitch_cap));
@@ -235,14 +248,29 @@ int bind_stripe(psa_stripe* s, int64_t n, int64_t m, int64_t c0, int64_t c1) {
 int rebuild_tables(psa_stripe* s, hipStream_t st, int nsym_known) {
     unsigned* meta = psa::alpha_meta(s->alpha);
     HIP_TRY(psa::launch_tables(s->a_dev, s->n, s->b_dev, s->W, s->alpha, s->a_ids, s->eqtab, s->tab_pitch, st));
-    unsigned k = (unsigned)nsym_known;
     if (nsym_known < 0) {
-        HIP_TRY(hipMemcpyAsync(&k, meta, sizeof k, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        // (no host round trip here: binding a pair must not wait for kernels that may be queued behind a fill which
+        // holds every SIMD of the chip)
+        HIP_TRY(hipMemcpyAsync(s->h_nsym, meta, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(s->tab_ev, st));
+        s->nsym_pending = true;
+        return PSA_OK;
     }
-    s->nsym = k;
+    s->nsym_pending = false;
+    s->nsym = (unsigned)nsym_known;
     const char* force = getenv("PSA_FILL_KERNEL");
-    s->use_v2 = k <= (unsigned)psa::kMaxSym && !(force && !strcmp(force, "v1"));
+    s->use_v2 = s->nsym <= (unsigned)psa::kMaxSym && !(force && !strcmp(force, "v1"));
+    return PSA_OK;
+}
+
+// Which fill kernel the stripe's current sequences take (table kernel: at most 32 distinct residues in A).
+int settle_tables(psa_stripe* s) {
+    if (!s->nsym_pending) return PSA_OK;
+    HIP_TRY(hipEventSynchronize(s->tab_ev));
+    s->nsym_pending = false;
+    s->nsym = *s->h_nsym;
+    const char* force = getenv("PSA_FILL_KERNEL");
+    s->use_v2 = s->nsym <= (unsigned)psa::kMaxSym && !(force && !strcmp(force, "v1"));
     return PSA_OK;
 }
 
@@ -293,6 +321,14 @@ int prepare_fill(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev,
             HIP_TRY(hipMemsetAsync(s->small, 0, 256, st));   // corner slots are recognised by their tag (a row number): none may survive a pass
         }
         HIP_TRY(hipMemsetAsync(s->ctrl + kAbortWord, 0, kCtrlLaunchBytes, st));
+        // Later chunks of this pass may be launched on OTHER streams (chunks in flight on alternating streams): they
+        // must not start before these memsets have run -- a strip of chunk 1 that finds a granule or corner tag left by
+        // the previous pass would run ahead of the strips it should follow, and a late memset would wipe what chunk 1
+        // has published.
+        HIP_TRY(hipEventRecord(s->pass_ev, st));
+        s->pass_stream = st;
+    } else if (st != s->pass_stream) {
+        HIP_TRY(hipStreamWaitEvent(st, s->pass_ev, 0));
     }
     // a control block of its own for every launch: the previous chunk's launch may still be running
     unsigned* launch_ctrl = s->ctrl + (s->launch_no++ % kCtrlRing) * (kCtrlLaunchBytes / sizeof(unsigned));
@@ -350,6 +386,7 @@ int fill_rows_impl(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_de
     hipStream_t st = (hipStream_t)stream;
     psa::FillArgs2 fb;
     bool with_codes = false;
+    if (int rc = settle_tables(s)) return rc;
     if (int rc = prepare_fill(s, r0, r1, left_dev, right_dev, st, o, &fb, &with_codes)) return rc;
     const char* prof_path = getenv("PSA_PROFILE_STRIPS");
     psa::u64* prof_dev = nullptr;
@@ -546,6 +583,7 @@ int psa_stripe_fill_flagged(psa_stripe* s, const int32_t* left_dev, const uint32
                             uint32_t* right_done, void* stream) {
     if (!s) return fail(PSA_E_ARG, "psa_stripe_fill_flagged: null stripe");
     if (s->band_rows) return fail(PSA_E_STATE, "psa_stripe_fill_flagged: a banded stripe is driven by psa_align_banded");
+    if (int rc = settle_tables(s)) return rc;
     if (!s->use_v2) return fail(PSA_E_STATE, "psa_stripe_fill_flagged: needs the v2 fill kernel (alphabet of at most 32 symbols)");
     if ((left_ready && !left_dev) || (right_done && !right_dev))
         return fail(PSA_E_ARG, "psa_stripe_fill_flagged: flags without their boundary buffer");
@@ -1330,6 +1368,7 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
     for (int k = 0; k < e->slots; ++k) {
         if (e->bound[k] != 1) continue;
         psa_stripe* s = e->st[k];
+        if (int rc = settle_tables(s)) return rc;
         if (!s->use_v2) {   // alphabets of more than 32 symbols: the generic kernel, a launch of its own
             if (int rc = fill_rows_impl(s, 0, s->n, nullptr, nullptr, st, FillOpts())) return rc;
             continue;

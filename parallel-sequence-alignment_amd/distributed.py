@@ -218,7 +218,8 @@ def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEng
     (ai, bj are empty arrays when traceback is False).  chunk_rows (multiple of 64; None or 0: chosen
     from the stripe width, auto_chunk_rows) is the hand-off granularity between neighbouring ranks.
     flagged=False: one fill launch per chunk (psa_stripe_fill_rows) instead of one launch over all rows whose
-    boundaries arrive and leave by flags (psa_stripe_fill_flagged, the default where the engine has it).
+    boundaries arrive and leave by flags (psa_stripe_fill_flagged, the default where the engine has it); there two
+    chunks are in flight at a time and must fit on the GPU together, so chunk_rows is capped at 24 576 (96 workgroups).
     """
     world, rank = dist.get_world_size(), dist.get_rank()
     a = np.ascontiguousarray(np.frombuffer(a, np.uint8) if isinstance(a, (bytes, bytearray)) else a, np.uint8)
@@ -227,6 +228,9 @@ def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEng
     if not chunk_rows:
         chunk_rows = auto_chunk_rows(max(1, m // world))
     assert chunk_rows >= 64 and chunk_rows % 64 == 0
+    # (launch-per-chunk path: two chunks are in flight, and every strip of chunk c+1 waits for strips of chunk c, which
+    # must be able to get a CU -- one workgroup of 256 rows per CU, 256 CUs: chunks beyond 96 workgroups are cut down)
+    max_chunk_rows = 256 * 96
     empty = np.zeros(0, np.int32)
     if n == 0 or m == 0:
         # no cell to fill: the final pick reads the boundary (simple.cpp:246 after an empty loop)
@@ -257,6 +261,7 @@ def align_striped(a, b, chunk_rows=None, traceback=True, engine_cls=HipStripeEng
                     raise
     if eng is not None and chunk_rows is not None:
         # (engines without the flagged fill, or flagged=False: one launch per chunk)
+        chunk_rows = min(chunk_rows, max_chunk_rows)
         # two chunks are in flight at a time (alternating streams): two boundary buffers each way
         left = [eng.new_edge(min(chunk_rows, n)) for _ in range(2)] if prev_owner is not None else None
         right = [eng.new_edge(min(chunk_rows, n)) for _ in range(2)] if next_owner is not None else None

@@ -379,6 +379,8 @@ def test_batch_packed_couples_match_oracle():
     big = len(seqs)
     seqs += [rng.integers(65, 69, 5800).astype(np.uint8), rng.integers(65, 69, 600).astype(np.uint8), np.zeros(0, np.uint8)]
     pairs += [(big, big + 1), (big, big + 1), (big + 2, big + 1), (big + 1, big + 1), (big + 1, base)]
+    if len(pairs) % 2 == 0:
+        pairs.append((base + 1, base + 2))
     assert len(pairs) % 2 == 1
     got = psa_amd.score_batch(seqs, pairs)
     for (i, j), g in zip(pairs, got):

@@ -1,6 +1,6 @@
 """Banded (linear-space) alignment against the plain one on the 2^15 pair: equality and time."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import psa_amd
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 15

@@ -1,7 +1,7 @@
 """Linear-space alignment at sizes whose codes strain or exceed HBM: 2^18 (plain vs banded, identical?)
 and 2^20 (banded only: 825 GB of codes would be needed otherwise)."""
 import os, sys, time, hashlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import psa_amd
 ks = [int(x) for x in sys.argv[1:]] or [18, 20]

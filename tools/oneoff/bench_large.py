@@ -1,6 +1,6 @@
 """One pair, larger than the headline size: score-only 2^17 / 2^18 and full alignment 2^17 (codes 12.9 GB)."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import psa_amd
 out = {}

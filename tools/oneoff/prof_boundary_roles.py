@@ -1,6 +1,6 @@
 """Diagnostic: end lag between consecutive strips of a lone score-only stripe (W = 16384) by boundary role."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import psa_amd
 k = 16; n = 1 << k; W = 16384

@@ -1,7 +1,7 @@
 """Diagnostic: fill time of very short matrices (1, 2, 4, 5, 8 strips) against a long B, to read
 the intrinsic per-step cost of each strip role.  Not part of the product."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import psa_amd
 m = 1 << 16

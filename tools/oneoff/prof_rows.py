@@ -1,6 +1,6 @@
 """Diagnostic: end times of the first strips for matrices of growing height against a fixed B.  Not part of the product."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import psa_amd
 m = 1 << 16

@@ -1,6 +1,6 @@
 """Diagnostic: per-strip timeline of psa_score(p) in one launch (PSA_PROFILE_STRIPES).  Not part of the product."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import psa_amd
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 16

@@ -1,6 +1,6 @@
 """Diagnostic: end lag between consecutive strips of a lone score-only fill as a function of the stripe width."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import psa_amd
 k = 16
