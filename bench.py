@@ -41,7 +41,9 @@ VALU_PEAK_TOPS = 39.3216      # 256 CU x 64 int32 lanes/clk x 2.4 GHz (tools/val
 # SURVEY's are kept beside them (frac_at_survey_ops) for comparison with round 1.
 OPS_PER_CELL_CODES = 11
 OPS_PER_CELL_SCORE = 8
-OPS_PER_CELL_BATCH = 10       # batch kernel: compares residues itself (v_cmp + v_cndmask) instead of a table byte
+OPS_PER_CELL_BATCH = 10       # batch kernel, int32 path: compares residues itself (v_cmp + v_cndmask) instead of a table byte
+OPS_PER_CELL_BATCH_PK = 12    # packed path: 12 instructions per step of TWO cells = 12 sixteen-bit lane operations per cell,
+PK_PEAK_TOPS = 2 * VALU_PEAK_TOPS   # against a peak of two 16-bit lane operations per lane and clock (v_pk_* are full rate: tools/pk_rate.hip)
 SURVEY_OPS_CODES, SURVEY_OPS_SCORE = 25, 10
 HBM_PEAK_GBS = 8000.0
 PROFILE_DIR = os.path.join("profiles", "r3")
@@ -475,7 +477,13 @@ def single_gpu(args):
         bench_batch.measure(nq=512, nt=256, L=512, reps=1, check=0)   # warm-up
         big = os.environ.get("PSA_BENCH_BATCH", "config5") == "config5"
         bb = bench_batch.measure(nq=100000 if big else 2048, nt=4096 if big else 256, L=512, reps=1 if big else 3, check=4, prewarm=not big)
-        bb["valu_frac"] = bb["gcups"] * OPS_PER_CELL_BATCH / 1e3 / VALU_PEAK_TOPS
+        packed = os.environ.get("PSA_BATCH_PACKED", "1") != "0"
+        bb["path"] = ("packed 16-bit, two pairs per lane (v_pk_add_u16 / v_pk_max_i16 / v_pk_min_u16): every couple of this "
+                      "block has second sequences of one length") if packed else "int32, one pair per wavefront (PSA_BATCH_PACKED=0)"
+        bb["ops_per_cell"] = OPS_PER_CELL_BATCH_PK if packed else OPS_PER_CELL_BATCH
+        bb["peak_unit"] = "T 16-bit lane operations / s (2 x the int32 peak)" if packed else "T int32 operations / s"
+        bb["valu_frac"] = (bb["gcups"] * OPS_PER_CELL_BATCH_PK / 1e3 / PK_PEAK_TOPS) if packed else (bb["gcups"] * OPS_PER_CELL_BATCH / 1e3 / VALU_PEAK_TOPS)
+        bb["valu_frac_note"] = "= VALU instructions issued (6 per cell packed, 10 int32) x 64 lanes / 39.3 T lane-instructions per second"
         bb["note"] = ("BASELINE config 5 on one GPU: 100 000 synthetic 512-residue queries x a block of 4 096 targets, every "
                       "pair, score only, sequences and pair list resident in HBM (the full all-vs-all is 5e9 pairs: a "
                       "stated block of it, SURVEY 8d)") if big else "reduced block (PSA_BENCH_BATCH != config5)"

@@ -226,22 +226,28 @@ __device__ __forceinline__ void batch_block_pk(BatchStripPk& S, const int2* row,
         if (act) { DOUT = pk_bits(D); H = pk_bits(Hn); V = pk_bits(Vn); }                                            \
         hv[k] = V;                                                                                                   \
     }
+    // lane 63's row leaves twice per block, eight slots at a time: slot of its column c = t - 63 is t + 1 = (D of column
+    // c - 1, V of column c).  Only lane 63 writes (the other lanes have nobody to hand their row to), and eight writes
+    // share ONE change of the execution mask (tools/pk_step.hip: per block 62, per step 63, unmasked writes of all lanes
+    // 67 cycles a step at four wavefronts per SIMD, where the arithmetic alone takes 55-60; eight steps of history fit
+    // the 128 registers of four wavefronts per SIMD, sixteen do not: 5 234 against 4 950 GCUPS).
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2i lds_v2i;
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2 += 2) {
         PSA_PK_STEP(k2, D0, D0, D1)
         PSA_PK_STEP(k2 + 1, D1, D1, D0)
+        if (k2 == 6 && publish) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) *(lds_v2i*)(pl + 2 * (k + 1)) = v2i{hd[k], hv[k]};
+        }
     }
 #undef PSA_PK_STEP
     S.D0 = D0; S.D1 = D1; S.H = H; S.V = V; S.fin1 = f1; S.fin2 = f2; S.fin3 = f3;
-    // lane 63's row leaves once per block: slot of its column c = t - 63 is t + 1 = (D of column c - 1, V of column c).
-    // Only lane 63 writes (the other lanes have nobody to hand their row to), and the sixteen writes share ONE change
-    // of the execution mask (tools/pk_step.hip: per block 62, per step 63, unmasked writes of all lanes 67 cycles a
-    // step at four wavefronts per SIMD, where the arithmetic alone takes 55-60).
+    // (second half of the block's hand-off, see above)
     if (publish) {
-        typedef int v2i __attribute__((ext_vector_type(2)));
-        typedef __attribute__((address_space(3))) v2i lds_v2i;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) *(lds_v2i*)(pl + 2 * (k + 1)) = v2i{hd[k], hv[k]};
+        for (int k = 8; k < 16; ++k) *(lds_v2i*)(pl + 2 * (k + 1)) = v2i{hd[k], hv[k]};
     }
 }
 
@@ -336,7 +342,7 @@ __device__ __forceinline__ void batch_couple_pk(const BatchArgs& p, const int64_
 // the int32 path one pair after the other.  Callers that want the packed rate list pairs that share a target (or
 // have targets of one length) next to each other -- an all-vs-all block ordered by target does (BASELINE config 5).
 #ifndef PSA_BATCH_MIN_WAVES
-#define PSA_BATCH_MIN_WAVES 3
+#define PSA_BATCH_MIN_WAVES 4
 #endif
 __global__ __launch_bounds__(kBatchWaves * 64) __attribute__((amdgpu_waves_per_eu(PSA_BATCH_MIN_WAVES, 8))) void batch_score_kernel(BatchArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
