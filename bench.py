@@ -95,6 +95,7 @@ def cpu_baseline(a, b, log2s=16):
            "sample": "prefix %dx%d of the workload pair, fill + codes + traceback, %d threads (oracle/psa_oracle.c "
                      "psa_oracle_align_mt), %.2f s" % (s, s, cores, dt),
            "score": int(sc)}
+    out["reference_binary"] = reference_binary_baseline(cores)
     seqdir = os.path.join(ROOT, "tests", "golden", "sequences")
     ta = np.frombuffer(psa_amd.read_fasta(os.path.join(seqdir, "titin_homo(50).fasta")), np.uint8)
     tb = np.frombuffer(psa_amd.read_fasta(os.path.join(seqdir, "titin_mus.fasta")), np.uint8)
@@ -105,6 +106,30 @@ def cpu_baseline(a, b, log2s=16):
                          "score": int(tsc), "alignment_len": int(len(tai)),
                          "sample": "the whole titin pair %d x %d, fill + codes + traceback" % (len(ta), len(tb))}
     return out
+
+
+def reference_binary_baseline(cores):
+    """The reference's own ./simple (oracle/_ref/simple: the reference's simple.cpp compiled where it lies by
+    oracle/Makefile, g++ -O2 -pthread; the binary travels with the tree, its sources do not) with p = the cores used,
+    on the pair its own timings.csv / report Table 1 were taken on (insulin-like, 1367 x 1373): the only size class it
+    can run -- it keeps an alignment vector in every cell, about 48 n m bytes and n^3 time."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "simple")
+    if not os.path.exists(exe):
+        return {"error": "oracle/_ref/simple is not built (the reference checkout was absent at build time)"}
+    cwd = os.path.join(ROOT, "tests", "golden")
+    a, b = "homo_insulinlike.fasta", "mouse_insulinlike.fasta"
+    try:
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, a, b, str(cores)], cwd=cwd, capture_output=True, timeout=120)
+        dt = time.perf_counter() - t0
+        first = r.stdout.split(b"\n")[0].decode()
+        n, m = 1367, 1373
+        return {"kind": "reference", "pair": "%s x %s (%d x %d)" % (a, b, n, m), "p": cores, "seconds": dt,
+                "value": n * m / dt / 1e9, "unit": "GCUPS", "mcups": n * m / dt / 1e6, "stdout_first_line": first,
+                "score_ok": first == "Score: 2616", "returncode": r.returncode}
+    except Exception as e:   # (a baseline leg: its failure is reported, the line stands)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def pmc_rows(name):
@@ -530,6 +555,7 @@ def huge_score_only(psa_amd, torch, k):
 def titin_figures(psa_amd, torch, np):
     """The titin pair (BASELINE config 3): device-resident fill + traceback through the stripe API, and the
     end-to-end time of psa_align from host buffers (second call onwards: the thread's stripe objects are reused)."""
+    out["reference_binary"] = reference_binary_baseline(cores)
     seqdir = os.path.join(ROOT, "tests", "golden", "sequences")
     ta = np.frombuffer(psa_amd.read_fasta(os.path.join(seqdir, "titin_homo(50).fasta")), np.uint8)
     tb = np.frombuffer(psa_amd.read_fasta(os.path.join(seqdir, "titin_mus.fasta")), np.uint8)

@@ -727,6 +727,10 @@ struct StripeSet {
 // call has the same shape (sizes, p, flags, device): no allocation on the second ./simple-style call.
 // Never freed by a destructor (the HIP runtime may be gone by then); psa_release_cache() frees it.
 thread_local StripeSet* g_cache = nullptr;
+}  // namespace
+void psa_drop_multi_cache_impl();   // (defined with the multi-GPU calls below)
+namespace {
+inline void drop_multi_fwd() { psa_drop_multi_cache_impl(); }
 
 int64_t chunk_rows_env() {
     if (const char* e = getenv("PSA_CHUNK_ROWS")) {
@@ -878,6 +882,7 @@ extern "C" {
 
 void psa_release_cache(void) {
     if (g_cache) { g_cache->clear(); delete g_cache; g_cache = nullptr; }
+    drop_multi_fwd();   // (the multi-GPU calls' objects)
 }
 
 int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, int32_t* score_out,
@@ -1030,7 +1035,11 @@ struct MultiRun {
     std::vector<int32_t*> edge;     // boundary g -> g+1 on dev[g+1]
     std::vector<uint32_t*> flags;
     int caller_dev = 0;
+    int64_t n = 0, m = 0;           // what the buffers were made for (the thread's cache: g_multi)
+    uint32_t mode = 0;
+    std::vector<int> dev_key;
     ~MultiRun() {
+        if (hipGetDevice(&caller_dev) != hipSuccess) caller_dev = 0;
         for (size_t g = 0; g < stream.size(); ++g) {
             if (!stream[g]) continue;
             hipSetDevice(dev[g]);
@@ -1048,11 +1057,58 @@ struct MultiRun {
 };
 
 // Fills every stripe; t = T1,T2,T3 at (n, m).  PSA_E_STATE (nothing launched) when a stripe needs the generic kernel.
+// The stripes, streams and boundary buffers of the calling thread's most recent multi-GPU call are kept and reused by the
+// next call of the same shape (sizes, devices, with or without codes), as psa_align does: psa_release_cache() frees them.
+thread_local MultiRun* g_multi = nullptr;
+
+}  // namespace
+void psa_drop_multi_cache_impl() { delete g_multi; g_multi = nullptr; }
+namespace {
+void drop_multi() { psa_drop_multi_cache_impl(); }
+
+int multi_launch(MultiRun& R, int64_t n, int32_t t[3]);
+
+int multi_fill_on(MultiRun& R, bool reuse, const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const int* devices, int ngpu,
+                  uint32_t flags, int32_t t[3]);
+
 int multi_fill(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const int* devices, int ngpu, uint32_t flags,
-               MultiRun& R, int32_t t[3]) {
+               MultiRun** out, int32_t t[3]) {
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    std::vector<int> key;
+    for (int id = 0; id < ngpu; ++id) key.push_back(devices ? devices[id] : (ndev > 0 ? id % ndev : 0));
+    const bool reuse = g_multi && g_multi->n == n && g_multi->m == m && g_multi->mode == flags && g_multi->dev_key == key;
+    if (!reuse) {
+        drop_multi();
+        g_multi = new MultiRun();
+    }
+    int rc = multi_fill_on(*g_multi, reuse, a, n, b, m, devices, ngpu, flags, t);
+    if (rc != PSA_OK) { drop_multi(); return rc; }
+    g_multi->n = n; g_multi->m = m; g_multi->mode = flags; g_multi->dev_key = key;
+    *out = g_multi;
+    return PSA_OK;
+}
+
+int multi_fill_on(MultiRun& R, bool reuse, const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const int* devices, int ngpu,
+                  uint32_t flags, int32_t t[3]) {
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     HIP_TRY(hipGetDevice(&R.caller_dev));
+    struct Back { int d; ~Back() { hipSetDevice(d); } } back{R.caller_dev};   // (the caller's device is current again on return)
+    if (reuse) {
+        const size_t G = R.st.size();
+        const size_t strips = (size_t)((n + 63) / 64);
+        for (size_t g = 0; g < G; ++g) {
+            HIP_TRY(hipSetDevice(R.dev[g]));
+            psa_stripe* s = R.st[g];
+            if (int rc = bind_stripe(s, n, m, s->c0, s->c1)) return rc;
+            if (int rc = upload_host(s, a, b, R.stream[g])) return rc;
+            if (!s->use_v2) return fail(PSA_E_STATE, "psa_align_multi: alphabet of more than %d symbols (generic kernel)", psa::kMaxSym);
+            if (g > 0) HIP_TRY(hipMemsetAsync(R.flags[g - 1], 0, sizeof(uint32_t) * (strips + 64), R.stream[g]));   // (its consumer's stream and device)
+        }
+        return multi_launch(R, n, t);
+    }
+    R.dev.clear();
     std::vector<std::pair<int64_t, int64_t>> cols;
     const int64_t block = m / ngpu;   // simple.cpp:90-99; zero-width stripes (ngpu > m) own no cell
     for (int id = 0; id < ngpu; ++id) {
@@ -1112,7 +1168,12 @@ int multi_fill(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const i
             HIP_TRY(hipDeviceSynchronize());
         }
     }
-    for (size_t g = 0; g < G; ++g) {   // sequences and tables in place before any fill is queued
+    return multi_launch(R, n, t);
+}
+
+int multi_launch(MultiRun& R, int64_t n, int32_t t[3]) {
+    const size_t G = R.st.size();
+    for (size_t g = 0; g < G; ++g) {   // sequences, tables and cleared flags in place before any fill is queued
         HIP_TRY(hipSetDevice(R.dev[g]));
         HIP_TRY(hipStreamSynchronize(R.stream[g]));
     }
@@ -1155,11 +1216,8 @@ int psa_score_multi(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, co
     if (int rc = multi_args_ok("psa_score_multi", n, a, m, b, ngpu)) return rc;
     if (n == 0 || m == 0) return psa_score(a, n, b, m, 1, score_out, triple_out);
     int32_t t[3];
-    int rc;
-    {
-        MultiRun R;
-        rc = multi_fill(a, n, b, m, devices, ngpu, 0, R, t);
-    }
+    MultiRun* R = nullptr;
+    const int rc = multi_fill(a, n, b, m, devices, ngpu, 0, &R, t);
     if (rc == PSA_E_STATE) return psa_score(a, n, b, m, ngpu, score_out, triple_out);   // generic kernel: this GPU only
     if (rc != PSA_OK) return rc;
     pick3(t, score_out);
@@ -1180,19 +1238,17 @@ int psa_align_multi(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, co
     if (!ai || !bj) { free(ai); free(bj); return fail(PSA_E_NOMEM, "psa_align_multi: host allocation failed"); }
     int32_t t[3], v = 0;
     int64_t len = 0;
-    int rc;
-    {
-        MultiRun R;
-        rc = multi_fill(a, n, b, m, devices, ngpu, PSA_F_TRACEBACK, R, t);
-        if (rc == PSA_OK) {
-            // the walk: right to left through the stripes, each on its own GPU, (i, j, k) handed on (psa.h)
-            int64_t i = n, j = m;
-            int k = pick3(t, &v);
-            for (size_t g = R.st.size(); g-- > 0 && rc == PSA_OK;) {
-                rc = psa_stripe_traceback(R.st[g], &i, &j, &k, ai, bj, cap, &len, R.stream[g]);
-                if (i == 0 || j == 0) break;
-            }
+    MultiRun* R = nullptr;
+    int rc = multi_fill(a, n, b, m, devices, ngpu, PSA_F_TRACEBACK, &R, t);
+    if (rc == PSA_OK) {
+        // the walk: right to left through the stripes, each on its own GPU, (i, j, k) handed on (psa.h)
+        int64_t i = n, j = m;
+        int k = pick3(t, &v);
+        for (size_t g = R->st.size(); g-- > 0 && rc == PSA_OK;) {
+            rc = psa_stripe_traceback(R->st[g], &i, &j, &k, ai, bj, cap, &len, R->stream[g]);
+            if (i == 0 || j == 0) break;
         }
+        if (rc != PSA_OK) drop_multi();
     }
     if (rc == PSA_E_STATE) { free(ai); free(bj); return psa_align(a, n, b, m, ngpu, score_out, ai_out, bj_out, len_out); }
     if (rc == PSA_OK) rc = psa_finish_alignment(ai, bj, len, cap, &len);
