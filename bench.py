@@ -555,7 +555,6 @@ def huge_score_only(psa_amd, torch, k):
 def titin_figures(psa_amd, torch, np):
     """The titin pair (BASELINE config 3): device-resident fill + traceback through the stripe API, and the
     end-to-end time of psa_align from host buffers (second call onwards: the thread's stripe objects are reused)."""
-    out["reference_binary"] = reference_binary_baseline(cores)
     seqdir = os.path.join(ROOT, "tests", "golden", "sequences")
     ta = np.frombuffer(psa_amd.read_fasta(os.path.join(seqdir, "titin_homo(50).fasta")), np.uint8)
     tb = np.frombuffer(psa_amd.read_fasta(os.path.join(seqdir, "titin_mus.fasta")), np.uint8)
