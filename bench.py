@@ -57,8 +57,10 @@ def parse():
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=0, help="rows per inter-GPU hand-off (N > 1, stripes); 0 = from the stripe width")
     ap.add_argument("--slots", type=int, default=16, help="pairs per launch (1..16); two engines take turns")
-    ap.add_argument("--overlap-fills", action="store_true",
-                    help="let the two engines' fill launches overlap (default: each fill launch alone on the chip)")
+    ap.add_argument("--engines", type=int, default=3, help="psa_many engines taking turns (2 or 3)")
+    ap.add_argument("--serial-fills", action="store_true",
+                    help="each fill launch alone on the chip (the next engine's fill waits for this one's end); default: "
+                         "the next launch is queued at once and fills the chip as this one drains")
     ap.add_argument("--mode", choices=["pairs", "stripes"], default="pairs",
                     help="N > 1: independent pairs per GPU plus the stripes figures (default), or only the stripes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -237,8 +239,9 @@ def throughput_job(engines, pairs, n, m, batches, serial_fills):
     holds pair s.  Returns (results [(slot, score, alignment length)], fill launch durations [(ms, pairs)], walk
     launch durations)."""
     S = engines[0].slots
+    E = len(engines)
     res, fills, walks = [], [], []
-    held = [0, 0]
+    held = [0] * E
 
     def collect(x):
         eng = engines[x]
@@ -260,12 +263,12 @@ def throughput_job(engines, pairs, n, m, batches, serial_fills):
                 eng.set_pair_dev(sl, pairs[sl][2].data_ptr(), n, pairs[sl][3].data_ptr(), m)
             else:
                 eng.clear_slot(sl)
-        eng.launch(engines[turn ^ 1] if serial_fills else None)
+        eng.launch(engines[(turn - 1) % E] if serial_fills else None)
         held[turn] = take
-        turn ^= 1
-    for x in (turn, turn ^ 1):
-        if held[x]:
-            collect(x)
+        turn = (turn + 1) % E
+    for x in range(E):
+        if held[(turn + x) % E]:
+            collect((turn + x) % E)
     return res, fills, walks
 
 
@@ -286,20 +289,23 @@ def single_gpu(args):
     S = min(16, max(1, args.slots))
     # (a slot holds n x m bytes of winner codes; two engines: keep a fifth of the device memory free)
     free_b, _total_b = torch.cuda.mem_get_info()
-    S = max(1, min(S, int(0.8 * free_b / (2.0 * (float(n) * m * 1.05 + (64 << 20))))))
+    E = 2 if args.serial_fills else max(2, min(3, args.engines))
+    if int(0.8 * free_b / (E * (float(n) * m * 1.05 + (64 << 20)))) < S:
+        E = 2
+    S = max(1, min(S, int(0.8 * free_b / (E * (float(n) * m * 1.05 + (64 << 20))))))
     pairs = slot_pairs(psa_amd, torch, k, S)
     a, b, a_dev, b_dev = pairs[0]
     gold = slot_goldens(k)
-    engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(2)]
-    serial = not args.overlap_fills
+    engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(E)]
+    serial = args.serial_fills
 
     # The timed region is `steps` alignments as an even number of equal launches (--steps 20: 10 + 10, one per
     # engine; the default 192: 12 launches of 16).  Warm-up: at least one launch of that size on EACH engine (its
     # ticket order, tables and code pages are then in place), more if --warmup asks for more alignments than that.
     batches = plan_batches(args.steps, S)
     per_launch = max(batches)
-    warm_launches = max(2, -(-args.warmup // per_launch))
-    warm_launches += warm_launches & 1
+    warm_launches = max(E, -(-args.warmup // per_launch))
+    warm_launches += (-warm_launches) % E
     throughput_job(engines, pairs, n, m, [per_launch] * warm_launches, serial)
     torch.cuda.synchronize()
     if dist:
@@ -362,7 +368,7 @@ def single_gpu(args):
                                   % (args.warmup, warm_launches, per_launch),
                    "results_checked": "%d of %d slots against tests/golden/oracle_only.json (score, alignment length); every "
                                       "slot equal across launches" % (checked, len(by_slot)),
-                   "fill_launches_overlap": bool(args.overlap_fills), "host_threads": 1,
+                   "fill_launches_overlap": not args.serial_fills, "host_threads": 1,
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
         "roofline": {"bound": "valu", "kernel": ("fill_strips_v2_dense<true>: ONE launch filling %d pairs (winner codes on), two wavefronts per SIMD" % per_launch_pairs)

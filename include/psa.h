@@ -101,9 +101,10 @@ double psa_multi_last_fill_ms(void);
  * pairs: a[k] (n[k] bytes) against b[k] (m[k] bytes); scores_out[k] = result.score, and -- when
  * ai_out, bj_out, len_out are not NULL -- (ai_out[k], bj_out[k], len_out[k]) = result.al.data of pair
  * k, each array released with psa_free().  Results are those of psa_align pair by pair.  Internally
- * two psa_many engines take turns: every batch is ONE fill launch over all its pairs (the strips of
- * the pairs interleaved, each pair advancing at the pace of its own chain) and ONE launch of their
- * traceback walks, which run beside the next batch's fill.  One host thread, two streams.
+ * three psa_many engines take turns (two where memory is short): every batch of up to 16 pairs is ONE fill
+ * launch over all its pairs (the strips of the pairs interleaved, each pair advancing at the pace of its
+ * own chain) and ONE launch of their traceback walks; a fill is queued while the one before it runs and
+ * takes over the chip as that one drains.  One host thread.
  */
 int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, const uint8_t* const* b,
                    const int64_t* m, int32_t* scores_out, int32_t** ai_out, int32_t** bj_out,
@@ -133,8 +134,12 @@ int psa_many_set_pair_dev(psa_many* e, int slot, const uint8_t* a_dev, int64_t n
                           int64_t m);
 int psa_many_clear_slot(psa_many* e, int slot);
 int psa_many_launch(psa_many* e);
-/* The same, but this engine's fill starts only when `after`'s fill launch has ended (NULL: at once):
- * two engines taking turns then keep every fill launch alone on the chip, beside the other's walks. */
+/* The same, but this engine's fill starts only when `after`'s fill launch has ended (NULL: at once): every fill launch
+ * then has the chip to itself.  Since round 3 psa_align_many does NOT do this: a fill launch queued behind another one
+ * fills the chip as that one drains (a launch of 16 pairs of 2^16 x 2^16 costs 4 ms of ramp and drain when it is alone:
+ * 62 against 67 ms for two launches), which needs the launch on the queue before the other drains -- so psa_many_launch
+ * never waits on the host, not even for the alphabet of a pair bound from device memory (a slot that turns out to have
+ * more than 32 distinct residues is redone with the generic kernel by psa_many_wait). */
 int psa_many_launch_after(psa_many* e, psa_many* after);
 int psa_many_wait(psa_many* e);
 int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_out[3], int32_t* ai,

@@ -1269,8 +1269,10 @@ struct psa_many {
     int64_t n_cap = 0, m_cap = 0;
     std::vector<psa_stripe*> st;
     std::vector<char> bound;        // 0: free, 1: holds a pair with cells, 2: holds a pair without cells (n or m is 0)
+    std::vector<char> unverified;   // the slot went into the table kernel's launch before its alphabet size was known (see launch)
     std::vector<int64_t> n, m;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // pair binding and the fill launch
+    hipStream_t walk_stream = nullptr;   // the walks and the copies of the results: highest priority (see psa_many_create)
     unsigned* ticket = nullptr;     // 256 bytes
     uint32_t* order = nullptr;
     size_t order_cap = 0;
@@ -1289,6 +1291,7 @@ void free_many(psa_many* e) {
     if (!e) return;
     DeviceGuard g(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
+    if (e->walk_stream) { hipStreamSynchronize(e->walk_stream); hipStreamDestroy(e->walk_stream); }
     for (auto* s : e->st) free_stripe(s);
     for (auto* p : e->h_ai) hipHostFree(p);
     for (auto* p : e->h_bj) hipHostFree(p);
@@ -1326,7 +1329,7 @@ int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uin
     psa_many* e = new psa_many();
     if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
     e->slots = slots; e->flags = flags; e->n_cap = n_cap; e->m_cap = m_cap;
-    e->bound.assign(slots, 0); e->n.assign(slots, 0); e->m.assign(slots, 0);
+    e->bound.assign(slots, 0); e->unverified.assign(slots, 0); e->n.assign(slots, 0); e->m.assign(slots, 0);
 #define MANY_TRY(expr)                                                                                         \
     do {                                                                                                       \
         hipError_t e_ = (expr);                                                                                \
@@ -1336,14 +1339,20 @@ int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uin
         }                                                                                                      \
     } while (0)
     {
-        // Engines alternate between two stream priorities: the runtime keeps a pool of hardware queues per priority,
-        // so two engines that take turns never share a hardware queue (kernels of one queue run in order: the
-        // fill of one engine would wait for the other's walks and copies instead of running beside them).
-        static std::atomic<unsigned> engines_made{0};
+        // Two streams per engine.  The fill launch of a batch wants every SIMD of the chip for 30 ms, and the next
+        // engine's fill, queued behind it, takes over as it drains: a walk (16 workgroups, 2 ms) or a result copy that
+        // waited its turn behind them would wait for a whole fill (seen: 29 ms), and with it the host that wants the
+        // results before it re-binds the engine.  So walks and copies go to a stream of the HIGHEST priority: they get
+        // slots that fill workgroups free ahead of the fill's own next workgroups (not reliably: a walk still waits
+        // 16-29 ms behind a full fill where it takes 2.3 ms on an idle chip, which is why psa_align_many lets three
+        // engines take turns).  Every fill stream has the SAME (normal) priority: with one engine's fill on the lowest
+        // priority the high-priority stream's wait for that fill never ended (two engines in flight: the queue
+        // scheduler starves the lowest class while a higher one has work, even work that waits for it).
         int least = 0, greatest = 0;
         MANY_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const int prio = (engines_made++ & 1u) ? greatest : (least + greatest) / 2;
+        const int prio = (least + greatest) / 2;
         MANY_TRY(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio));
+        MANY_TRY(hipStreamCreateWithPriority(&e->walk_stream, hipStreamNonBlocking, greatest));
     }
     for (auto& x : e->ev) MANY_TRY(hipEventCreate(&x));
     MANY_TRY(hipMalloc(&e->ticket, 256));
@@ -1366,6 +1375,8 @@ int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uin
     // hardware queue under resident fills was seen to stall them for seconds under a profiler)
     MANY_TRY(hipMemsetAsync(e->ticket, 0, 256, e->stream));
     MANY_TRY(hipStreamSynchronize(e->stream));
+    MANY_TRY(hipMemsetAsync(e->ticket, 0, 256, e->walk_stream));
+    MANY_TRY(hipStreamSynchronize(e->walk_stream));
 #undef MANY_TRY
     *out = e;
     return PSA_OK;
@@ -1424,7 +1435,18 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
     for (int k = 0; k < e->slots; ++k) {
         if (e->bound[k] != 1) continue;
         psa_stripe* s = e->st[k];
-        if (int rc = settle_tables(s)) return rc;
+        // A pair bound from DEVICE memory: how many distinct residues A has comes back with the table kernels, which
+        // may sit behind another engine's fill for milliseconds.  The launch does not wait for them (the host would
+        // then queue this fill only when the other has drained, and the chip would idle through every drain): the
+        // slot goes into the table kernel's launch as if its alphabet fitted (at most 32 symbols: every protein and
+        // nucleotide alphabet), the count is looked at when the results are collected, and a slot whose alphabet
+        // did not fit is filled and walked again there with the generic kernel (psa_many_wait).
+        e->unverified[k] = 0;
+        if (s->nsym_pending) {
+            const char* force = getenv("PSA_FILL_KERNEL");
+            if (force && !strcmp(force, "v1")) { if (int rc = settle_tables(s)) return rc; }
+            else { s->use_v2 = true; e->unverified[k] = 1; }
+        }
         if (!s->use_v2) {   // alphabets of more than 32 symbols: the generic kernel, a launch of its own
             if (int rc = fill_rows_impl(s, 0, s->n, nullptr, nullptr, st, FillOpts())) return rc;
             continue;
@@ -1465,7 +1487,10 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
                                     nj > 1 ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes, st, nj > 1 && dense_ok)) return rc;
     } else HIP_TRY(hipEventRecord(e->ev[0], st));
     HIP_TRY(hipEventRecord(e->ev[1], st));
-    // the walks: one wavefront per pair, all in one launch, each starting from its pair's final pick
+    // the walks: one workgroup per pair, all in one launch, each starting from its pair's final pick; they and the
+    // copies of the results go to the engine's high-priority stream, behind the fill
+    st = e->walk_stream;
+    HIP_TRY(hipStreamWaitEvent(st, e->ev[1], 0));
     if (with_codes) {
         psa::TraceBatch tb;
         memset(&tb, 0, sizeof tb);
@@ -1509,6 +1534,35 @@ int psa_many_wait(psa_many* e) {
     if (g.rc) return g.rc;
     HIP_TRY(hipEventSynchronize(e->ev[3]));
     e->launched = false;
+    // slots that were launched before their alphabet size was known (psa_many_launch_after): the count is on the host
+    // now; a slot with more than 32 distinct residues did not belong in the table kernel -- again, generic kernel
+    const bool with_codes = (e->flags & PSA_F_TRACEBACK) != 0;
+    for (int k = 0; k < e->slots; ++k) {
+        if (e->bound[k] != 1 || !e->unverified[k]) continue;
+        e->unverified[k] = 0;
+        psa_stripe* s = e->st[k];
+        if (int rc = settle_tables(s)) return rc;
+        if (s->use_v2) continue;
+        hipStream_t st = e->stream;
+        if (int rc = fill_rows_impl(s, 0, s->n, nullptr, nullptr, st, FillOpts())) return rc;
+        if (with_codes) {
+            psa::TraceBatch tb;
+            memset(&tb, 0, sizeof tb);
+            if (int rc = make_trace_args(s, TraceOpts(), &tb.job[0])) return rc;
+            tb.job[0].start_triple = s->small + kFinalWord;
+            tb.njobs = 1;
+            HIP_TRY(psa::launch_traceback_many(psa::kWalkPair, tb, 1, st));
+        }
+        HIP_TRY(hipMemcpyAsync(e->h_triple + 4 * k, s->small + kFinalWord, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(e->h_abort + k, s->ctrl + kAbortWord, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        if (with_codes) {
+            HIP_TRY(hipMemcpyAsync(e->h_state + 16 * k, s->tb_state, sizeof(int64_t) * 12, hipMemcpyDeviceToHost, st));
+            const size_t cnt = (size_t)(s->n + s->W + 2);
+            HIP_TRY(hipMemcpyAsync(e->h_ai[k], s->tb_ai, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(e->h_bj[k], s->tb_bj, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return PSA_OK;
 }
 
@@ -1573,13 +1627,23 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
         n_cap = std::max(n_cap, n[k]); m_cap = std::max(m_cap, m[k]);
         if (want_al) { ai_out[k] = bj_out[k] = nullptr; len_out[k] = 0; }
     }
-    // slots per engine: what fits in half of the free device memory, at most 8 (two engines: 16 pairs in flight)
+    // Engines and slots.  A fill launch costs about 4 ms beyond 1.75 ms per 2^16 pair (its ramp and drain), so launches
+    // of up to 16 pairs (what a launch's argument block holds); three engines taking turns where the device memory
+    // holds them -- each fill is then queued while the one before it runs and takes over the chip as that one drains,
+    // and nobody waits for an engine's walks, which get their turn at the next drain --, else two, each fill after the
+    // other's end (the walks and copies of one beside the fill of the other).  70 % of the free memory at most.
     psa_release_cache();
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double per_slot = (want_al ? (double)n_cap * (double)m_cap * 1.05 : 0.0) + 64.0 * (double)(n_cap + m_cap) + (1 << 20);
-    int slots = (int)std::min<double>(8.0, 0.5 * (double)free_b / (2.0 * per_slot));
-    slots = (int)std::min<int64_t>(slots, (npairs + 1) / 2);
+    const double budget = 0.7 * (double)free_b;
+    int E = 3;
+    int slots = (int)std::min<double>(16.0, budget / (3.0 * per_slot));
+    if (slots < 8 || npairs <= 2 * (int64_t)slots) {   // (few pairs, or little memory: two engines with more slots each)
+        E = 2;
+        slots = (int)std::min<double>(16.0, budget / (2.0 * per_slot));
+    }
+    slots = (int)std::min<int64_t>(slots, (npairs + E - 1) / E);
     if (slots < 1) {
         // not even one pair per engine fits with its codes: one at a time through psa_align (linear space if need be)
         for (int64_t k = 0; k < npairs; ++k) {
@@ -1588,8 +1652,8 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
         }
         return PSA_OK;
     }
-    psa_many* eng[2] = {nullptr, nullptr};
-    std::vector<int64_t> held[2];
+    psa_many* eng[3] = {nullptr, nullptr, nullptr};
+    std::vector<int64_t> held[3];
     int rc = PSA_OK;
     auto collect = [&](int x) -> int {
         if (int r = psa_many_wait(eng[x])) return r;
@@ -1606,19 +1670,19 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
         held[x].clear();
         return PSA_OK;
     };
-    for (int x = 0; x < 2 && rc == PSA_OK; ++x) rc = psa_many_create(&eng[x], slots, n_cap, m_cap, want_al ? PSA_F_TRACEBACK : 0);
+    for (int x = 0; x < E && rc == PSA_OK; ++x) rc = psa_many_create(&eng[x], slots, n_cap, m_cap, want_al ? PSA_F_TRACEBACK : 0);
     int turn = 0;
-    for (int64_t k0 = 0; k0 < npairs && rc == PSA_OK; k0 += slots, turn ^= 1) {
+    for (int64_t k0 = 0; k0 < npairs && rc == PSA_OK; k0 += slots, turn = (turn + 1) % E) {
         if (!held[turn].empty()) rc = collect(turn);
         for (int sl = 0; sl < slots && rc == PSA_OK; ++sl) {
             const int64_t k = k0 + sl;
             if (k < npairs) { rc = psa_many_set_pair(eng[turn], sl, a[k], n[k], b[k], m[k]); held[turn].push_back(k); }
             else rc = psa_many_clear_slot(eng[turn], sl);
         }
-        if (rc == PSA_OK) rc = psa_many_launch_after(eng[turn], eng[turn ^ 1]);
+        if (rc == PSA_OK) rc = (E == 3) ? psa_many_launch(eng[turn]) : psa_many_launch_after(eng[turn], eng[turn ^ 1]);
     }
-    for (int x = 0; x < 2 && rc == PSA_OK; ++x) if (!held[x].empty()) rc = collect(x);
-    for (int x = 0; x < 2; ++x) free_many(eng[x]);
+    for (int x = 0; x < E && rc == PSA_OK; ++x) if (!held[(turn + x) % E].empty()) rc = collect((turn + x) % E);
+    for (int x = 0; x < E; ++x) free_many(eng[x]);
     if (rc != PSA_OK && want_al)
         for (int64_t k = 0; k < npairs; ++k) { free(ai_out[k]); free(bj_out[k]); ai_out[k] = bj_out[k] = nullptr; }
     return rc;

@@ -538,6 +538,26 @@ def test_many_engine_reuse_and_device_inputs():
             res = eng.result(sl, a.size, b.size)
             sc, ai, bj = O.align(a, b)
             assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (rnd, sl)
+    # Pairs bound from device memory go into the launch before their alphabet size is back on the host (the launch never
+    # waits on the host); a pair with more than 32 distinct residues is found out when the results are collected and
+    # redone with the generic kernel -- beside ordinary pairs of the same launch, twice in a row.
+    for rnd in range(2):
+        items = []
+        for sl, (lo, hi) in enumerate(((40, 100), (65, 69), (33, 120))):
+            n, m = int(rng.integers(100, 3000)), int(rng.integers(100, 3500))
+            a = rng.integers(lo, hi, n).astype(np.uint8)
+            b = np.where(rng.random(m) < 0.5, np.resize(a, m), rng.integers(lo, hi, m)).astype(np.uint8)
+            ta, tb = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+            items.append((a, b, ta, tb))
+        torch.cuda.synchronize()
+        for sl, (a, b, ta, tb) in enumerate(items):
+            eng.set_pair_dev(sl, ta.data_ptr(), a.size, tb.data_ptr(), b.size)
+        eng.launch()
+        eng.wait()
+        for sl, (a, b, ta, tb) in enumerate(items):
+            res = eng.result(sl, a.size, b.size)
+            sc, ai, bj = O.align(a, b)
+            assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), ("wide alphabet", rnd, sl)
     eng.close()
 
 
