@@ -81,8 +81,7 @@ void psa_release_cache(void);
  * memory of GPU g+1 that GPU g's fill writes directly (peer access over xGMI) and GPU g+1's fill polls: no
  * collective library, no launcher, no host loop while the fills run.  The walk goes right to left through the
  * stripes, each on its own GPU.  Result = psa_align's for any ngpu.  A device may be named more than once if the
- * stripes that share it fit on it together (ceil(n / 256) workgroups each, one per compute unit); ngpu = 1, or
- * an alphabet of more than 32 symbols, is psa_align(p = ngpu) on the current GPU.  Needs hipDeviceCanAccessPeer
+ * stripes that share it fit on it together (ceil(n / 256) workgroups each, one per compute unit).  Needs hipDeviceCanAccessPeer
  * between neighbours.  psa_score_multi: the same without traceback storage (BASELINE config 4, 2^20 x 2^20).
  * The `./simple` front end calls psa_align_multi when PSA_GPUS=N (N > 1) is set in the environment.
  */
@@ -138,8 +137,8 @@ int psa_many_launch(psa_many* e);
  * then has the chip to itself.  Since round 3 psa_align_many does NOT do this: a fill launch queued behind another one
  * fills the chip as that one drains (a launch of 16 pairs of 2^16 x 2^16 costs 4 ms of ramp and drain when it is alone:
  * 62 against 67 ms for two launches), which needs the launch on the queue before the other drains -- so psa_many_launch
- * never waits on the host, not even for the alphabet of a pair bound from device memory (a slot that turns out to have
- * more than 32 distinct residues is redone with the generic kernel by psa_many_wait). */
+ * never waits on the host, not even for the alphabet of a pair bound from device memory (the table kernel takes any
+ * byte alphabet). */
 int psa_many_launch_after(psa_many* e, psa_many* after);
 int psa_many_wait(psa_many* e);
 int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_out[3], int32_t* ai,

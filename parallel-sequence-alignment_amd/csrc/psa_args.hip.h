@@ -48,7 +48,7 @@ constexpr int kFrontWord = 32;  // control block: [0] ticket, [1] abort flag, [3
 // Bounded waiting inside kernels: wall-clock time (s_memrealtime, 100 MHz), see Spin in psa_fill_v2.hip.h
 constexpr unsigned long long kSpinTicks = 30ull * 100000000ull;   // 30 s
 constexpr int kNW = 4;         // strips (wavefronts) per workgroup
-constexpr int kMaxSym = 32;    // rows of the substitution table
+constexpr int kMaxSym = 256;   // rows of the substitution table: one per distinct residue of A (only the rows of residues that occur are built)
 constexpr int kTabPad = 16;    // table words (8 columns each) of padding in front of a row
 
 struct FillArgs2 {

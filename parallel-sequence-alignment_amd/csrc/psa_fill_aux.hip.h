@@ -32,9 +32,9 @@ __global__ void build_eqtab(const uint8_t* b, int W, const unsigned* meta, const
                             int pitch) {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;  // word index inside the row
     const unsigned sym = blockIdx.y;
-    if (w >= pitch) return;
+    if (w >= pitch || sym >= meta[0]) return;   // (rows of residues that do not occur in A are never read: a_ids < meta[0])
     uint32_t word = 0x06060606u;
-    if (sym < meta[0] && sym < (unsigned)kMaxSym) {
+    if (sym < (unsigned)kMaxSym) {
         const int c0 = (w - kTabPad) * 4;
         const unsigned ch = inv[sym];
 #pragma unroll

@@ -1,4 +1,4 @@
-// psa_fill_v2.hip.h -- the production fill kernel for gfx950 (alphabets of <= 32 symbols).
+// psa_fill_v2.hip.h -- the production fill kernel for gfx950 (any byte alphabet: a table row per distinct residue of A).
 //
 // Same mathematics and the same outputs as fill_strips_v1 (psa_fill_v1.hip.h), organised for a short
 // dependent instruction stream per anti-diagonal step: at 2^16 x 2^16 one pair is bound by the length of

@@ -263,7 +263,8 @@ int rebuild_tables(psa_stripe* s, hipStream_t st, int nsym_known) {
     return PSA_OK;
 }
 
-// Which fill kernel the stripe's current sequences take (table kernel: at most 32 distinct residues in A).
+// Which fill kernel the stripe's current sequences take (the table kernel, unless A has more distinct residues than the
+// table has rows -- kMaxSym = 256: never -- or PSA_FILL_KERNEL=v1 asks for the generic kernel).
 int settle_tables(psa_stripe* s) {
     if (!s->nsym_pending) return PSA_OK;
     HIP_TRY(hipEventSynchronize(s->tab_ev));
@@ -584,7 +585,7 @@ int psa_stripe_fill_flagged(psa_stripe* s, const int32_t* left_dev, const uint32
     if (!s) return fail(PSA_E_ARG, "psa_stripe_fill_flagged: null stripe");
     if (s->band_rows) return fail(PSA_E_STATE, "psa_stripe_fill_flagged: a banded stripe is driven by psa_align_banded");
     if (int rc = settle_tables(s)) return rc;
-    if (!s->use_v2) return fail(PSA_E_STATE, "psa_stripe_fill_flagged: needs the v2 fill kernel (alphabet of at most 32 symbols)");
+    if (!s->use_v2) return fail(PSA_E_STATE, "psa_stripe_fill_flagged: needs the table fill kernel (PSA_FILL_KERNEL=v1 is set)");
     if ((left_ready && !left_dev) || (right_done && !right_dev))
         return fail(PSA_E_ARG, "psa_stripe_fill_flagged: flags without their boundary buffer");
     FillOpts o;
@@ -1103,7 +1104,7 @@ int multi_fill_on(MultiRun& R, bool reuse, const uint8_t* a, int64_t n, const ui
             psa_stripe* s = R.st[g];
             if (int rc = bind_stripe(s, n, m, s->c0, s->c1)) return rc;
             if (int rc = upload_host(s, a, b, R.stream[g])) return rc;
-            if (!s->use_v2) return fail(PSA_E_STATE, "psa_align_multi: alphabet of more than %d symbols (generic kernel)", psa::kMaxSym);
+            if (!s->use_v2) return fail(PSA_E_STATE, "psa_align_multi: the generic kernel is forced (PSA_FILL_KERNEL=v1; %d table rows)", psa::kMaxSym);
             if (g > 0) HIP_TRY(hipMemsetAsync(R.flags[g - 1], 0, sizeof(uint32_t) * (strips + 64), R.stream[g]));   // (its consumer's stream and device)
         }
         return multi_launch(R, n, t);
@@ -1146,7 +1147,7 @@ int multi_fill_on(MultiRun& R, bool reuse, const uint8_t* a, int64_t n, const ui
         if (rc == PSA_OK) rc = bind_stripe(s, n, m, cols[g].first, cols[g].second);
         if (rc == PSA_OK) rc = upload_host(s, a, b, st);
         if (rc != PSA_OK) return rc;
-        if (!s->use_v2) return fail(PSA_E_STATE, "psa_align_multi: alphabet of more than %d symbols (generic kernel)", psa::kMaxSym);
+        if (!s->use_v2) return fail(PSA_E_STATE, "psa_align_multi: the generic kernel is forced (PSA_FILL_KERNEL=v1; %d table rows)", psa::kMaxSym);
         if (g + 1 < G) {
             if (R.dev[g] != R.dev[g + 1]) {
                 int can = 0;
@@ -1269,7 +1270,6 @@ struct psa_many {
     int64_t n_cap = 0, m_cap = 0;
     std::vector<psa_stripe*> st;
     std::vector<char> bound;        // 0: free, 1: holds a pair with cells, 2: holds a pair without cells (n or m is 0)
-    std::vector<char> unverified;   // the slot went into the table kernel's launch before its alphabet size was known (see launch)
     std::vector<int64_t> n, m;
     hipStream_t stream = nullptr;        // pair binding and the fill launch
     hipStream_t walk_stream = nullptr;   // the walks and the copies of the results: highest priority (see psa_many_create)
@@ -1329,7 +1329,7 @@ int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uin
     psa_many* e = new psa_many();
     if (hipGetDevice(&e->device) != hipSuccess) e->device = 0;
     e->slots = slots; e->flags = flags; e->n_cap = n_cap; e->m_cap = m_cap;
-    e->bound.assign(slots, 0); e->unverified.assign(slots, 0); e->n.assign(slots, 0); e->m.assign(slots, 0);
+    e->bound.assign(slots, 0); e->n.assign(slots, 0); e->m.assign(slots, 0);
 #define MANY_TRY(expr)                                                                                         \
     do {                                                                                                       \
         hipError_t e_ = (expr);                                                                                \
@@ -1437,17 +1437,14 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         psa_stripe* s = e->st[k];
         // A pair bound from DEVICE memory: how many distinct residues A has comes back with the table kernels, which
         // may sit behind another engine's fill for milliseconds.  The launch does not wait for them (the host would
-        // then queue this fill only when the other has drained, and the chip would idle through every drain): the
-        // slot goes into the table kernel's launch as if its alphabet fitted (at most 32 symbols: every protein and
-        // nucleotide alphabet), the count is looked at when the results are collected, and a slot whose alphabet
-        // did not fit is filled and walked again there with the generic kernel (psa_many_wait).
-        e->unverified[k] = 0;
+        // then queue this fill only when the other has drained): the table kernel takes any alphabet (a table row
+        // per distinct byte value, kMaxSym = 256), so the count only matters when the generic kernel is forced.
         if (s->nsym_pending) {
             const char* force = getenv("PSA_FILL_KERNEL");
             if (force && !strcmp(force, "v1")) { if (int rc = settle_tables(s)) return rc; }
-            else { s->use_v2 = true; e->unverified[k] = 1; }
+            else s->use_v2 = true;
         }
-        if (!s->use_v2) {   // alphabets of more than 32 symbols: the generic kernel, a launch of its own
+        if (!s->use_v2) {   // the generic kernel (PSA_FILL_KERNEL=v1): a launch of its own
             if (int rc = fill_rows_impl(s, 0, s->n, nullptr, nullptr, st, FillOpts())) return rc;
             continue;
         }
@@ -1534,35 +1531,6 @@ int psa_many_wait(psa_many* e) {
     if (g.rc) return g.rc;
     HIP_TRY(hipEventSynchronize(e->ev[3]));
     e->launched = false;
-    // slots that were launched before their alphabet size was known (psa_many_launch_after): the count is on the host
-    // now; a slot with more than 32 distinct residues did not belong in the table kernel -- again, generic kernel
-    const bool with_codes = (e->flags & PSA_F_TRACEBACK) != 0;
-    for (int k = 0; k < e->slots; ++k) {
-        if (e->bound[k] != 1 || !e->unverified[k]) continue;
-        e->unverified[k] = 0;
-        psa_stripe* s = e->st[k];
-        if (int rc = settle_tables(s)) return rc;
-        if (s->use_v2) continue;
-        hipStream_t st = e->stream;
-        if (int rc = fill_rows_impl(s, 0, s->n, nullptr, nullptr, st, FillOpts())) return rc;
-        if (with_codes) {
-            psa::TraceBatch tb;
-            memset(&tb, 0, sizeof tb);
-            if (int rc = make_trace_args(s, TraceOpts(), &tb.job[0])) return rc;
-            tb.job[0].start_triple = s->small + kFinalWord;
-            tb.njobs = 1;
-            HIP_TRY(psa::launch_traceback_many(psa::kWalkPair, tb, 1, st));
-        }
-        HIP_TRY(hipMemcpyAsync(e->h_triple + 4 * k, s->small + kFinalWord, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(e->h_abort + k, s->ctrl + kAbortWord, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        if (with_codes) {
-            HIP_TRY(hipMemcpyAsync(e->h_state + 16 * k, s->tb_state, sizeof(int64_t) * 12, hipMemcpyDeviceToHost, st));
-            const size_t cnt = (size_t)(s->n + s->W + 2);
-            HIP_TRY(hipMemcpyAsync(e->h_ai[k], s->tb_ai, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(e->h_bj[k], s->tb_bj, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
-        }
-        HIP_TRY(hipStreamSynchronize(st));
-    }
     return PSA_OK;
 }
 

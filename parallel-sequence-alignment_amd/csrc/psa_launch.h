@@ -22,7 +22,7 @@ hipError_t launch_fill_v1_score(const FillArgs& fa, unsigned strips, hipStream_t
 // FASTA-to-device encoding of one stripe (psa_fill_aux.hip.h): alphabet of A -> ids of A's rows -> table of B
 hipError_t launch_tables(const uint8_t* a_dev, int64_t n, const uint8_t* b_dev, int W, uint8_t* alpha, uint8_t* a_ids,
                          uint32_t* eqtab, int tab_pitch, hipStream_t st);
-constexpr size_t kAlphaBytes = 256 * 4 + 16 + 256 + 32;   // present[256] (u32) | meta[4] (u32) | map[256] | inv[32]
+constexpr size_t kAlphaBytes = 256 * 4 + 16 + 256 + 256;   // present[256] (u32) | meta[4] (u32) | map[256] | inv[256]
 inline unsigned* alpha_meta(uint8_t* alpha) { return (unsigned*)alpha + 256; }
 
 hipError_t launch_edge_post(const int32_t* packed, int64_t r0, int64_t rows, int64_t n, int32_t* plane, uint32_t* flags, hipStream_t st);

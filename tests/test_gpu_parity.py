@@ -478,15 +478,22 @@ def test_banded_through_env_and_large(monkeypatch):
     assert banded.score == sc and np.array_equal(banded.ai, ai) and np.array_equal(banded.bj, bj)
 
 
-def test_banded_generic_kernels_and_tiny():
-    """Banded mode with the generic kernels (more than 32 symbols -> fill_strips_v1) and degenerate sizes."""
+def test_banded_generic_kernels_and_tiny(monkeypatch):
+    """Banded mode on a 60-symbol alphabet and degenerate sizes: with the table kernel (a table row per distinct
+    residue: any byte alphabet) and with the generic kernel fill_strips_v1 (PSA_FILL_KERNEL=v1), plain and banded."""
     rng = np.random.default_rng(5)
     a = rng.integers(40, 100, 777).astype(np.uint8)      # 60 symbols
     b = rng.integers(40, 100, 555).astype(np.uint8)
-    for x, y in ((a, b), (a[:1], b), (a, b[:1]), (a[:300], a[:300])):
-        res = psa_amd.align(x, y, 1, band_rows=256)
-        sc, ai, bj = O.align(x, y)
-        assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (x.size, y.size)
+    wide = (rng.integers(0, 256, 900).astype(np.uint8), rng.integers(0, 256, 700).astype(np.uint8))   # every byte value
+    for force in (None, "v1"):
+        if force:
+            monkeypatch.setenv("PSA_FILL_KERNEL", force)
+        for x, y in ((a, b), (a[:1], b), (a, b[:1]), (a[:300], a[:300]), wide):
+            sc, ai, bj = O.align(x, y)
+            for band in (256, None):
+                res = psa_amd.align(x, y, 1, band_rows=band)
+                assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (force, band, x.size, y.size)
+            assert psa_amd.score(x, y, 3) == sc
 
 
 def test_align_many_matches_oracle():
@@ -539,8 +546,8 @@ def test_many_engine_reuse_and_device_inputs():
             sc, ai, bj = O.align(a, b)
             assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (rnd, sl)
     # Pairs bound from device memory go into the launch before their alphabet size is back on the host (the launch never
-    # waits on the host); a pair with more than 32 distinct residues is found out when the results are collected and
-    # redone with the generic kernel -- beside ordinary pairs of the same launch, twice in a row.
+    # waits on the host; the table kernel takes any byte alphabet): 60- and 87-symbol pairs beside an ordinary one in the
+    # same launch, twice in a row.
     for rnd in range(2):
         items = []
         for sl, (lo, hi) in enumerate(((40, 100), (65, 69), (33, 120))):
@@ -741,7 +748,7 @@ def test_align_multi_stripes_as_separate_launches(golden_dir):
         res = psa_amd.align_multi(x, y, devices=[0, 0, 0])          # (ngpu > m: zero-width stripes own no cell)
         sc, ai, bj = O.align(x, y)
         assert (res.score, list(res.ai), list(res.bj)) == (sc, list(ai), list(bj)), (x, y)
-    # more than 32 symbols: the generic kernel, on the current GPU
+    # a 60-symbol alphabet
     a = rng.integers(40, 100, 777).astype(np.uint8)
     b = rng.integers(40, 100, 555).astype(np.uint8)
     sc, ai, bj = O.align(a, b)
