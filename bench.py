@@ -8,9 +8,9 @@ final pick, traceback walk, prefix fix-up (what run() does in simple.cpp:261-294
 resident in HBM before the timed region.  N = 1: the synthetic 2^16 x 2^16 protein pair of BASELINE
 config 4 on one GPU.  One pair alone cannot fill the GPU (its anti-diagonal dependency chain is
 n + m steps long whatever the hardware), so the job is what psa_align_many does: ONE host thread
-drives two psa_many engines that take turns; every batch of --slots pairs is ONE fill launch (the
-pairs' strips interleaved) and ONE launch of their walks, and the walks and copies of one batch run
-beside the fill of the next.  "value" is the job's throughput, "one_pair_alone" the latency of a
+drives up to three psa_many engines that take turns; every batch of --slots pairs (20: what a launch's
+argument block holds) is ONE fill launch (the pairs' strips interleaved) and ONE launch of their walks,
+and the walks and copies of one batch run beside the fill of the next.  "value" is the job's throughput, "one_pair_alone" the latency of a
 single alignment, and the roofline object is the dominant kernel -- the fill launch -- timed live
 with HIP events on the engine's stream inside the timed region.
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank does the same with its own
@@ -43,6 +43,7 @@ OPS_PER_CELL_CODES = 11
 OPS_PER_CELL_SCORE = 8
 OPS_PER_CELL_BATCH = 10       # batch kernel, int32 path: compares residues itself (v_cmp + v_cndmask) instead of a table byte
 OPS_PER_CELL_BATCH_PK = 12    # packed path: 12 instructions per step of TWO cells = 12 sixteen-bit lane operations per cell,
+MAX_SLOTS = 20   # pairs per fill launch: what the kernel's 4 KB argument block holds (psa_args.hip.h, kMaxJobs)
 PK_PEAK_TOPS = 2 * VALU_PEAK_TOPS   # against a peak of two 16-bit lane operations per lane and clock (v_pk_* are full rate: tools/pk_rate.hip)
 SURVEY_OPS_CODES, SURVEY_OPS_SCORE = 25, 10
 HBM_PEAK_GBS = 8000.0
@@ -52,11 +53,11 @@ PROFILE_DIR = os.path.join("profiles", "r3")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=192)
+    ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=0, help="rows per inter-GPU hand-off (N > 1, stripes); 0 = from the stripe width")
-    ap.add_argument("--slots", type=int, default=16, help="pairs per launch (1..16); two engines take turns")
+    ap.add_argument("--slots", type=int, default=MAX_SLOTS, help="pairs per launch (1..%d); up to three engines take turns" % MAX_SLOTS)
     ap.add_argument("--engines", type=int, default=3, help="psa_many engines taking turns (2 or 3)")
     ap.add_argument("--serial-fills", action="store_true",
                     help="each fill launch alone on the chip (the next engine's fill waits for this one's end); default: "
@@ -224,18 +225,17 @@ def slot_goldens(k):
 
 
 def plan_batches(count, S):
-    """`count` alignments as an even number (>= 2) of launches of equal size (two engines take turns: both get the
-    same number of launches), at most S pairs each."""
-    if count <= 1:
-        return [count] if count else []
-    L = max(2, -(-count // S))
-    L += L & 1
+    """`count` alignments as the fewest launches of at most S pairs, of equal size (a launch costs about 4 ms of ramp
+    and drain beyond its pairs)."""
+    if count <= 0:
+        return []
+    L = -(-count // S)
     base, rem = divmod(count, L)
     return [base + (1 if x < rem else 0) for x in range(L)]
 
 
-def throughput_job(engines, pairs, n, m, batches, serial_fills):
-    """sum(batches) complete alignments through two engines that take turns, ONE host thread; slot s of every launch
+def throughput_job(engines, pairs, n, m, batches, serial_fills, ref_event=None, fill_ends=None):
+    """sum(batches) complete alignments through the engines, which take turns, ONE host thread; slot s of every launch
     holds pair s.  Returns (results [(slot, score, alignment length)], fill launch durations [(ms, pairs)], walk
     launch durations)."""
     S = engines[0].slots
@@ -251,6 +251,8 @@ def throughput_job(engines, pairs, n, m, batches, serial_fills):
             res.append((sl, r.score, len(r.ai)))
         f, w = eng.last_ms()
         fills.append((f, held[x])); walks.append(w)
+        if ref_event is not None:
+            fill_ends.append(eng.fill_ms_since(ref_event) + (held[x],))
         held[x] = 0
 
     turn = 0
@@ -286,23 +288,25 @@ def single_gpu(args):
         dist, backend = init_dist(local)
     k = args.log2n
     n = m = 1 << k
-    S = min(16, max(1, args.slots))
-    # (a slot holds n x m bytes of winner codes; two engines: keep a fifth of the device memory free)
+    S = min(MAX_SLOTS, max(1, args.slots))
+    # (a slot holds n x m bytes of winner codes; slots before engines: 20 + 20 rather than 3 x 13; a twentieth of the
+    # device memory stays free)
     free_b, _total_b = torch.cuda.mem_get_info()
-    E = 2 if args.serial_fills else max(2, min(3, args.engines))
-    if int(0.8 * free_b / (E * (float(n) * m * 1.05 + (64 << 20)))) < S:
-        E = 2
-    S = max(1, min(S, int(0.8 * free_b / (E * (float(n) * m * 1.05 + (64 << 20))))))
+    slot_b = float(n) * m * 1.02 + (64 << 20)
+    fit = int(0.95 * free_b / slot_b)
+    S = max(1, min(S, fit // 2 if args.steps > S else fit))
+    batches = plan_batches(args.steps, S)
+    E = 2 if args.serial_fills else max(1, min(3, args.engines))
+    E = max(1, min(E, len(batches), fit // S))
     pairs = slot_pairs(psa_amd, torch, k, S)
     a, b, a_dev, b_dev = pairs[0]
     gold = slot_goldens(k)
     engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(E)]
-    serial = args.serial_fills
+    serial = args.serial_fills and E > 1
 
-    # The timed region is `steps` alignments as an even number of equal launches (--steps 20: 10 + 10, one per
-    # engine; the default 192: 12 launches of 16).  Warm-up: at least one launch of that size on EACH engine (its
+    # The timed region is `steps` alignments as the fewest launches of equal size (--steps 20: ONE launch of 20 on one
+    # engine; the default 240: 12 launches of 20, three engines taking turns).  Warm-up: at least one launch of that size on EACH engine (its
     # ticket order, tables and code pages are then in place), more if --warmup asks for more alignments than that.
-    batches = plan_batches(args.steps, S)
     per_launch = max(batches)
     warm_launches = max(E, -(-args.warmup // per_launch))
     warm_launches += (-warm_launches) % E
@@ -311,8 +315,12 @@ def single_gpu(args):
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    ref = torch.cuda.Event(enable_timing=True)
+    ref.record()
+    ref.synchronize()
+    fill_ends = []
     t0 = time.perf_counter()
-    res, fills, walks = throughput_job(engines, pairs, n, m, batches, serial)
+    res, fills, walks = throughput_job(engines, pairs, n, m, batches, serial, ref.cuda_event, fill_ends)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -343,9 +351,25 @@ def single_gpu(args):
         e.close()
 
     # ---- the dominant kernel: the fill launch over S pairs, HIP events on the engine's stream, timed region ----
+    # One engine: the events in front of and behind the launch bracket it.  Several engines: the fills are queued together
+    # and the chip takes workgroups from all of them (the event in front of a fill fires when it is QUEUED; the fills of
+    # three engines end within a few ms of each other, fill_end_ms), so what a launch costs is the time from the first
+    # launch's begin (queued on an idle chip) to the last launch's end, divided by the number of launches.
     full = [f for f, cnt in fills if cnt == per_launch]
     per_launch_pairs = per_launch
-    fill_ms = sum(full) / len(full)
+    ends = sorted(t1_ for _, t1_, _ in fill_ends)
+    overlapped = E > 1 and not serial and len(ends) > 2 and all(cnt == per_launch for _, _, cnt in fill_ends)
+    if overlapped:
+        first_begin = min(t0_ for t0_, _, _ in fill_ends)
+        fill_ms = (ends[-1] - first_begin) / len(ends)
+        fill_ms_note = ("(end of the last fill launch - begin of the first) / %d launches of the timed region, HIP events on the "
+                        "engines' fill streams: the launches of the %d engines are queued together and share the chip (their "
+                        "start-to-end durations, fill_start_to_end_ms and rocprofv3's kernel trace, overlap and sum to more "
+                        "than the time that passed); one launch alone on the chip: roofline.alone" % (len(ends), E))
+    else:
+        fill_ms = sum(full) / len(full)
+        fill_ms_note = ("HIP events around the fill launch on the engine's stream, every launch of the timed region"
+                        + ("; the other engine's walks (one wavefront per pair) run beside it" if E > 1 else ""))
     achieved = per_launch_pairs * cells1 * OPS_PER_CELL_CODES / (fill_ms * 1e-3) / 1e12
     aggregate = cells1 * OPS_PER_CELL_CODES * args.steps / dt / 1e12
     grid = per_launch_pairs * ((n + 255) // 256)
@@ -358,17 +382,17 @@ def single_gpu(args):
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "synthetic iid 20-letter protein pair 2^%d x 2^%d (mt19937_64 seeds 0xA/0xB0000000+%d), "
                                "fill with one-byte winner codes in HBM + traceback walk + prefix fix-up; one step = one "
-                               "complete alignment per GPU; ONE host thread, two engines taking turns, %d DISTINCT pairs per "
+                               "complete alignment per GPU; ONE host thread, %d engine%s, %d DISTINCT pairs per "
                                "fill launch and per walk launch (slot s: seeds +0x100*s; psa_many / psa_align_many); no "
-                               "inter-GPU communication" % (k, k, k, per_launch),
+                               "inter-GPU communication" % (k, k, k, E, " (one launch holds the whole timed region)" if E == 1 else "s taking turns", per_launch),
                    "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1, "pairs_per_launch": per_launch,
-                   "launch_sizes_timed": batches, "engine_slots": S,
+                   "launch_sizes_timed": batches, "engine_slots": S, "engines": E,
                    "warmup_alignments_run": per_launch * warm_launches,
                    "warmup_note": "--warmup %d asked; run: %d launches of %d (one full launch on EACH engine at least)"
                                   % (args.warmup, warm_launches, per_launch),
                    "results_checked": "%d of %d slots against tests/golden/oracle_only.json (score, alignment length); every "
                                       "slot equal across launches" % (checked, len(by_slot)),
-                   "fill_launches_overlap": not args.serial_fills, "host_threads": 1,
+                   "fill_launches_overlap": not serial and E > 1, "host_threads": 1,
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
         "roofline": {"bound": "valu", "kernel": ("fill_strips_v2_dense<true>: ONE launch filling %d pairs (winner codes on), two wavefronts per SIMD" % per_launch_pairs)
@@ -380,8 +404,8 @@ def single_gpu(args):
                                  "compares per aggregate, which this kernel does not do (frac_at_survey_ops keeps that scale)",
                      "valu_insts_per_cell_executed": pmc_valu_per_cell("<true>(psa::FillBatch)", grid * 256, per_launch_pairs * cells1),
                      "kernel_ms": fill_ms, "launches_timed": len(full),
-                     "kernel_ms_note": "HIP events around the fill launch on the engine's stream, every launch of the timed "
-                                       "region; the other engine's walks (one wavefront per pair) run beside it",
+                     "kernel_ms_note": fill_ms_note,
+                     "fill_end_ms": [round(t, 3) for t in ends], "fill_start_to_end_ms": [round(f, 3) for f, _ in fills],
                      "fill_gcups": per_launch_pairs * cells1 / (fill_ms * 1e-3) / 1e9,
                      "aggregate_achieved": aggregate, "aggregate_frac": aggregate / VALU_PEAK_TOPS,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (separate --pmc passes)",
@@ -455,6 +479,22 @@ def single_gpu(args):
     out["roofline"]["one_pair_alone"] = {"kernel_ms": fill1, "frac": cells1 * OPS_PER_CELL_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                                          "frac_at_survey_ops": cells1 * SURVEY_OPS_CODES / (fill1 * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                                          "structural_ceiling": min(1.0, cells1 / ((n + m) * 65536.0))}
+    if overlapped:
+        # the same launch alone on the chip: start-to-end duration, HIP events in front of and behind it (what rocprofv3's
+        # kernel trace calls its duration)
+        al = psa_amd.Many(per_launch, n, m, traceback=True)
+        fa = []
+        for rep in range(3):
+            for sl in range(per_launch):
+                al.set_pair_dev(sl, pairs[sl][2].data_ptr(), n, pairs[sl][3].data_ptr(), m)
+            al.launch()
+            al.wait()
+            fa.append(al.last_ms()[0])
+        al.close()
+        ms_al = sum(fa[1:]) / len(fa[1:])
+        out["roofline"]["alone"] = {"kernel_ms": ms_al, "pairs": per_launch,
+                                    "frac": per_launch * cells1 * OPS_PER_CELL_CODES / (ms_al * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                    "note": "one launch with the chip to itself, start to end (ramp and drain included)"}
     out["one_pair_alone"] = {"ms": lat_ms, "gcups": cells1 / (lat_ms * 1e-3) / 1e9, "fill_ms": fill1, "traceback_ms": walk1}
     if stripes_info is not None:
         out["stripes"] = stripes_info

@@ -100,9 +100,10 @@ double psa_multi_last_fill_ms(void);
  * pairs: a[k] (n[k] bytes) against b[k] (m[k] bytes); scores_out[k] = result.score, and -- when
  * ai_out, bj_out, len_out are not NULL -- (ai_out[k], bj_out[k], len_out[k]) = result.al.data of pair
  * k, each array released with psa_free().  Results are those of psa_align pair by pair.  Internally
- * three psa_many engines take turns (two where memory is short): every batch of up to 16 pairs is ONE fill
+ * the pairs go in as few batches of equal size as possible, a batch being up to PSA_MANY_MAX_SLOTS pairs: ONE fill
  * launch over all its pairs (the strips of the pairs interleaved, each pair advancing at the pace of its
- * own chain) and ONE launch of their traceback walks; a fill is queued while the one before it runs and
+ * own chain) and ONE launch of their traceback walks.  Up to three psa_many engines take turns (one when a
+ * single batch holds every pair; two where memory is short): a fill is queued while the one before it runs and
  * takes over the chip as that one drains.  One host thread.
  */
 int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, const uint8_t* const* b,
@@ -110,12 +111,14 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
                    int64_t* len_out);
 
 /* The engine behind it, for callers whose pairs are resident in device memory or who run their own
- * loop.  `slots` (1..16) pairs of up to n_cap x m_cap are in flight per launch; flags: PSA_F_TRACEBACK
+ * loop.  `slots` (1..PSA_MANY_MAX_SLOTS) pairs of up to n_cap x m_cap are in flight per launch; flags: PSA_F_TRACEBACK
  * for alignments, 0 for scores.  All device and pinned host buffers are allocated by create; the
  * other calls allocate nothing on the device (a changed set of pair sizes re-uploads a few KB of
  * ticket order).  An engine owns a stream; calls on one engine must not overlap, engines are independent.
- *   set_pair / set_pair_dev  bind a slot to a pair (host / device residues; copies and the encoding
- *                            kernels are queued on the engine's stream); clear_slot leaves it out
+ *   set_pair / set_pair_dev  bind a slot to a pair; clear_slot leaves it out.  Host residues are copied at once (the
+ *                            caller's buffers are its own again on return).  Device residues are NOT read before the
+ *                            next launch, whose binding kernels copy and encode the pairs of all slots together:
+ *                            they must stay valid and unchanged until that launch's results have been waited for
  *   launch                   queue ONE fill launch over all bound slots, ONE launch of their walks and
  *                            the copies of the results to pinned host memory; returns at once
  *   wait                     block until those results are on the host
@@ -125,6 +128,7 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
  *   last_ms                  device time of the last launch's fill and of its walks (HIP events on
  *                            the engine's stream)
  */
+#define PSA_MANY_MAX_SLOTS 20   /* what the 4 KB argument block of a fill launch holds */
 typedef struct psa_many psa_many;
 int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uint32_t flags);
 void psa_many_destroy(psa_many* e);
@@ -135,8 +139,8 @@ int psa_many_clear_slot(psa_many* e, int slot);
 int psa_many_launch(psa_many* e);
 /* The same, but this engine's fill starts only when `after`'s fill launch has ended (NULL: at once): every fill launch
  * then has the chip to itself.  Since round 3 psa_align_many does NOT do this: a fill launch queued behind another one
- * fills the chip as that one drains (a launch of 16 pairs of 2^16 x 2^16 costs 4 ms of ramp and drain when it is alone:
- * 62 against 67 ms for two launches), which needs the launch on the queue before the other drains -- so psa_many_launch
+ * fills the chip as that one drains (a launch of 2^16 x 2^16 pairs costs 4 ms of ramp and drain when it is alone:
+ * 62 against 67 ms for two launches of 16 pairs), which needs the launch on the queue before the other drains -- so psa_many_launch
  * never waits on the host, not even for the alphabet of a pair bound from device memory (the table kernel takes any
  * byte alphabet). */
 int psa_many_launch_after(psa_many* e, psa_many* after);
@@ -144,6 +148,12 @@ int psa_many_wait(psa_many* e);
 int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_out[3], int32_t* ai,
                     int32_t* bj, int64_t cap, int64_t* len_out);
 int psa_many_last_ms(psa_many* e, float* fill_ms_out, float* walk_ms_out);
+/* Where the last launch's fill sits on the device's time line: milliseconds from `ref_event` (a hipEvent_t of the caller,
+ * recorded with timing on this device and already reached) to the events the engine recorded in front of and behind its
+ * fill launch.  With several engines in flight a fill is queued while the one before it runs, so the event in front of it
+ * says when it was queued, not when it began: the spacing of the END times of consecutive launches is what a launch costs
+ * then (bench.py).  No counterpart in the reference (measurement only). */
+int psa_many_fill_ms_since(psa_many* e, void* ref_event, float* begin_ms_out, float* end_ms_out);
 int64_t psa_many_code_bytes(const psa_many* e, int slot);
 
 /*

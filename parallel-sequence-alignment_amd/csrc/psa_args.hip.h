@@ -15,6 +15,7 @@ struct FillArgs {
     int W;                   // stripe width (>= 1)
     int Q;                   // blocks of 64 steps per strip = ceil((W+63)/64)
     int Wpad;                // ring pitch (granules per parity)
+    int tab_pitch;           // fill v2: words per row of the substitution table (FillArgs2::eqtab); here to keep the block at 200 bytes
     const int32_t* left;     // [3][R] plain T1,T2,T3 at column c0 for rows r0+1..r1; null = column 0
     const int32_t* corner;   // [4] plain triple at (r0, c0) and the tag r0, when left != null and r0 > 0: published by
     int32_t* corner_next;    // the chunk above (its first strip stores {left triple of row r1, tag r1} here), which may
@@ -54,9 +55,8 @@ constexpr int kTabPad = 16;    // table words (8 columns each) of padding in fro
 struct FillArgs2 {
     FillArgs base;
     const uint8_t* a_ids;     // symbol id (< kMaxSym) of every row of A
-    const uint32_t* eqtab;    // [kMaxSym][tab_pitch] words, byte c%4 of word kTabPad + c/4 = score(sym, B[c]): a byte, so that
+    const uint32_t* eqtab;    // [kMaxSym][base.tab_pitch] words, byte c%4 of word kTabPad + c/4 = score(sym, B[c]): a byte, so that
                               // the step adds it with an SDWA byte select and needs no extract
-    int tab_pitch;
 };
 
 // One launch can fill several stripes at once -- of different pairs, or the column stripes of one pair.
@@ -66,13 +66,47 @@ struct FillArgs2 {
 // together they keep every CU busy, which one 2^16 pair alone cannot (its chain is n + m steps long
 // whatever the hardware).  A workgroup only ever waits for workgroups with lower tickets, which run
 // already or have finished: no assumption on dispatch order or residency.
-constexpr int kMaxJobs = 16;
+constexpr int kMaxJobs = 20;          // 20 x 200 bytes + 24: the most a 4 KB kernel argument block holds
 constexpr int kOrderJobShift = 24;   // order[t] = job << 24 | group
+static_assert(sizeof(FillArgs2) == 200 && kMaxJobs * sizeof(FillArgs2) + 24 <= 4096, "FillBatch must stay within the 4 KB argument block");
 struct FillBatch {
     FillArgs2 job[kMaxJobs];
     int njobs;
     const uint32_t* order;        // null: one job, group = ticket
     unsigned* ticket;             // launch-wide ticket counter, zeroed before the launch
+};
+
+// ---- binding the pairs of a multi-pair launch (psa_fill_aux.hip.h: bind_stage / bind_alphabet / bind_tables): what
+// the engine would otherwise queue per slot (two copies, six memsets, four small kernels) as three launches over all slots
+constexpr int kBindRegions = 4;
+struct BindJob {
+    const uint8_t* src_a;    // residues to copy into the slot's own buffers; null: already there (or the slot is only cleared)
+    const uint8_t* src_b;
+    uint8_t* a;              // the slot's A (n bytes) and B (W bytes)
+    uint8_t* b;
+    int64_t n;
+    int W;
+    int pitch;               // words per row of eqtab
+    unsigned* alpha;         // present[256] | meta[4] | map[256 bytes] | inv[256 bytes]; present is all zero between launches
+    uint8_t* ids;            // symbol id of every row of A
+    uint32_t* eqtab;
+    void* clear[kBindRegions];             // regions the fill must find zeroed (ring, corner slots, control blocks),
+    unsigned clear_bytes[kBindRegions];    // multiples of 16 bytes, 16-byte aligned; 0 = none
+    int tables;              // 1: the slot holds a new pair (copy, alphabet, ids, table); 0: only the regions are cleared
+    int pad_;
+};
+struct BindBatch {
+    BindJob job[kMaxJobs];
+    int njobs;
+};
+// results of a multi-pair launch gathered into one block per slot (one copy to the host instead of three per slot):
+// words 0..23 the walk's state (12 x int64), 24..26 the final triple, 27 the fill's abort word
+constexpr int kResultWords = 32;
+struct CollectJob { const int64_t* state; const int32_t* triple; const unsigned* abort_flag; int slot; int pad_; };
+struct CollectBatch {
+    CollectJob job[kMaxJobs];
+    int njobs;
+    int32_t* out;            // [slots][kResultWords]
 };
 
 // ---- traceback walk (replaces the per-cell alignment vectors of simple.cpp:164-211) ----
@@ -94,7 +128,7 @@ struct TraceArgs {
     const int32_t* start_triple;   // not null: the walk starts at (n, c0 + W) in the table the final pick of this
                                    // triple names (simple.cpp:246-256) instead of at state[0..2]
 };
-constexpr int kMaxWalks = 16;
+constexpr int kMaxWalks = 20;
 struct TraceBatch {          // one wavefront (workgroup) per walk
     TraceArgs job[kMaxWalks];
     int njobs;

@@ -28,6 +28,30 @@ hipError_t launch_tables(const uint8_t* a_dev, int64_t n, const uint8_t* b_dev, 
     return hipGetLastError();
 }
 
+hipError_t launch_bind(const BindBatch& bb, hipStream_t st) {
+    if (bb.njobs < 1) return hipSuccess;
+    int64_t most = 0;
+    bool tables = false;
+    for (int j = 0; j < bb.njobs; ++j) {
+        const BindJob& q = bb.job[j];
+        for (int r = 0; r < kBindRegions; ++r) most = std::max<int64_t>(most, q.clear_bytes[r] / 16);
+        if (q.tables) { tables = true; most = std::max<int64_t>(most, std::max<int64_t>(q.n, (int64_t)kMaxSym * q.pitch / 8)); }
+    }
+    const unsigned blocks = (unsigned)std::min<int64_t>(256, std::max<int64_t>(1, (most + 1023) / 1024));
+    hipLaunchKernelGGL(bind_stage, dim3(blocks, bb.njobs), dim3(256), 0, st, bb);
+    if (tables) {
+        hipLaunchKernelGGL(bind_alphabet, dim3(bb.njobs), dim3(256), 0, st, bb);
+        hipLaunchKernelGGL(bind_tables, dim3(blocks, bb.njobs), dim3(256), 0, st, bb);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_collect(const CollectBatch& cb, hipStream_t st) {
+    if (cb.njobs < 1) return hipSuccess;
+    hipLaunchKernelGGL(collect_results, dim3(cb.njobs), dim3(kResultWords), 0, st, cb);
+    return hipGetLastError();
+}
+
 hipError_t launch_edge_post(const int32_t* packed, int64_t r0, int64_t rows, int64_t n, int32_t* plane, uint32_t* flags, hipStream_t st) {
     const unsigned blocks = (unsigned)std::min<int64_t>((3 * rows + 255) / 256, 1024);
     hipLaunchKernelGGL(edge_scatter, dim3(blocks), dim3(256), 0, st, packed, r0, rows, n, plane);

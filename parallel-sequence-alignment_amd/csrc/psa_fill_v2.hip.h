@@ -635,7 +635,7 @@ __device__ __forceinline__ void fill_strips_body(const FillBatch& B) {
 
     // ---- substitution table row of this lane; window of 16 columns starting at t0 - lane ----
     const int sym = row_ok ? (int)q.a_ids[i - 1] : 0;
-    c.trow = q.eqtab + (size_t)sym * q.tab_pitch + kTabPad;
+    c.trow = q.eqtab + (size_t)sym * q.base.tab_pitch + kTabPad;
     c.msh = 8 * ((64 - lane) & 3);                      // (t0 - lane) mod 4 bytes, t0 % 16 == 0
     c.mword_idx = (-lane - ((64 - lane) & 3)) / 4;      // floor((0 - lane) / 4), exact division
 #pragma unroll

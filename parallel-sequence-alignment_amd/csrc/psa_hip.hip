@@ -118,7 +118,11 @@ struct psa_stripe {
     unsigned launch_no = 0;
     // v2 kernel: symbol ids of A and the per-symbol substitution table of this stripe's B
     uint8_t* a_ids = nullptr;
-    uint8_t* alpha = nullptr;    // present[256] (u32) | meta[4] (u32) | map[256] | inv[32]
+    uint8_t* alpha = nullptr;    // present[256] (u32) | meta[4] (u32) | map[256] | inv[256]
+    // engine slots (psa_many): a pair bound since the last launch is copied and encoded by the launch's binding kernels
+    const uint8_t* src_a = nullptr;   // device residues to copy from (null: already in a_dev / b_dev)
+    const uint8_t* src_b = nullptr;
+    bool rebind = false;
     uint32_t* eqtab = nullptr;
     unsigned nsym = 0;
     bool use_v2 = false;
@@ -220,6 +224,7 @@ int alloc_stripe(psa_stripe** out, int64_t n_cap, int W_cap, uint32_t flags, boo
     CREATE_TRY(hipMalloc(&s->alpha, kAlphaBytes));
     CREATE_TRY(hipMalloc(&s->eqtab, sizeof(uint32_t) * (size_t)psa::kMaxSym * (size_t)s->pitch_cap));
     CREATE_TRY(hipMemset(s->ctrl, 0, kCtrlBytes));
+    CREATE_TRY(hipMemset(s->alpha, 0, kAlphaBytes));
 #undef CREATE_TRY
     *out = s;
     return PSA_OK;
@@ -296,6 +301,8 @@ struct FillOpts {
     bool any_order = false;          // do not insist on r0 == end of the previous chunk
     const unsigned* left_done = nullptr;   // the stripe on the left is filled by the same launch (see FillArgs)
     unsigned* right_done = nullptr;
+    psa::BindJob* clear_into = nullptr;    // not null: the caller zeroes what the fill must find zeroed (one kernel over all its
+                                           // stripes: launch_bind) -- the regions are listed here instead of memsets on the stream
 };
 
 // Everything a fill of rows r0+1..r1 needs before its kernel can be launched (memsets on `st`), and the kernel
@@ -316,6 +323,12 @@ int prepare_fill(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev,
         // is recognised by its tag (strip number), and a strip that finds a left-over with the right tag
         // runs ahead of the strips it should follow and overwrites ring slots they have not read yet.
         // (A banded refill takes its input from the checkpoint row, never from the ring.)
+        if (o.clear_into) {
+            o.clear_into->clear[0] = s->ring; o.clear_into->clear_bytes[0] = (unsigned)(sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64));
+            o.clear_into->clear[1] = s->ctrl + kAbortWord; o.clear_into->clear_bytes[1] = (unsigned)kCtrlLaunchBytes;
+            if (r0 == 0) { s->corner_cur = 0; o.clear_into->clear[2] = s->small; o.clear_into->clear_bytes[2] = 256; }
+            s->pass_stream = st;   // (no later chunks on other streams in this mode)
+        } else {
         HIP_TRY(hipMemsetAsync(s->ring, 0, sizeof(psa::u64) * (2 * (size_t)s->Wpad + 64), st));
         if (r0 == 0) {
             s->corner_cur = 0;
@@ -328,12 +341,14 @@ int prepare_fill(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev,
         // has published.
         HIP_TRY(hipEventRecord(s->pass_ev, st));
         s->pass_stream = st;
+        }
     } else if (st != s->pass_stream) {
         HIP_TRY(hipStreamWaitEvent(st, s->pass_ev, 0));
     }
     // a control block of its own for every launch: the previous chunk's launch may still be running
     unsigned* launch_ctrl = s->ctrl + (s->launch_no++ % kCtrlRing) * (kCtrlLaunchBytes / sizeof(unsigned));
-    HIP_TRY(hipMemsetAsync(launch_ctrl, 0, kCtrlLaunchBytes, st));
+    if (o.clear_into) { o.clear_into->clear[3] = launch_ctrl; o.clear_into->clear_bytes[3] = (unsigned)kCtrlLaunchBytes; }
+    else HIP_TRY(hipMemsetAsync(launch_ctrl, 0, kCtrlLaunchBytes, st));
     psa::FillArgs fa;
     fa.a = s->a_dev; fa.b = s->b_dev; fa.n = s->n; fa.r0 = r0; fa.r1 = r1; fa.c0 = s->c0;
     fa.W = o.W > 0 ? o.W : s->W; fa.Q = o.W > 0 ? steps_q(o.W) : s->Q; fa.Wpad = s->Wpad;
@@ -351,7 +366,7 @@ int prepare_fill(psa_stripe* s, int64_t r0, int64_t r1, const int32_t* left_dev,
     fa.abort_flag = s->ctrl + kAbortWord;
     fa.prof = nullptr;
     fa.ckpt = s->ckpt; fa.band_strips = s->band_rows / 64;
-    out->base = fa; out->a_ids = s->a_ids; out->eqtab = s->eqtab; out->tab_pitch = s->tab_pitch;
+    out->base = fa; out->a_ids = s->a_ids; out->eqtab = s->eqtab; out->base.tab_pitch = s->tab_pitch;
     *with_codes_out = with_codes;
     s->corner_cur = (s->corner_cur + 1) % kCornerSlots;
     s->next_r0 = r1;
@@ -1277,9 +1292,8 @@ struct psa_many {
     uint32_t* order = nullptr;
     size_t order_cap = 0;
     std::vector<unsigned> order_sig;   // group counts the order on the device was built for
-    int64_t* h_state = nullptr;     // pinned: slots x 16
-    int32_t* h_triple = nullptr;    // pinned: slots x 4
-    unsigned* h_abort = nullptr;    // pinned: slots
+    int32_t* d_res = nullptr;       // slots x kResultWords: walk state, final triple, abort word of every slot (collect_results)
+    int32_t* h_res = nullptr;       // pinned copy
     std::vector<int32_t*> h_ai, h_bj;   // pinned: reversed columns as the walk emitted them
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // fill start / end, walks end, results on the host
     bool launched = false;
@@ -1295,8 +1309,8 @@ void free_many(psa_many* e) {
     for (auto* s : e->st) free_stripe(s);
     for (auto* p : e->h_ai) hipHostFree(p);
     for (auto* p : e->h_bj) hipHostFree(p);
-    hipFree(e->ticket); hipFree(e->order);
-    hipHostFree(e->h_state); hipHostFree(e->h_triple); hipHostFree(e->h_abort);
+    hipFree(e->ticket); hipFree(e->order); hipFree(e->d_res);
+    hipHostFree(e->h_res);
     for (auto& x : e->ev) if (x) hipEventDestroy(x);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -1356,9 +1370,8 @@ int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uin
     }
     for (auto& x : e->ev) MANY_TRY(hipEventCreate(&x));
     MANY_TRY(hipMalloc(&e->ticket, 256));
-    MANY_TRY(hipHostMalloc(&e->h_state, sizeof(int64_t) * 16 * slots));
-    MANY_TRY(hipHostMalloc(&e->h_triple, sizeof(int32_t) * 4 * slots));
-    MANY_TRY(hipHostMalloc(&e->h_abort, sizeof(unsigned) * slots));
+    MANY_TRY(hipMalloc(&e->d_res, sizeof(int32_t) * psa::kResultWords * slots));
+    MANY_TRY(hipHostMalloc(&e->h_res, sizeof(int32_t) * psa::kResultWords * slots));
     for (int k = 0; k < slots; ++k) {
         psa_stripe* s = nullptr;
         if (int rc = alloc_stripe(&s, n_cap, (int)m_cap, flags, false)) { free_many(e); return rc; }
@@ -1389,7 +1402,14 @@ int psa_many_set_pair(psa_many* e, int slot, const uint8_t* a, int64_t n, const 
     if (e->bound[slot] != 1) return PSA_OK;
     DeviceGuard g(e->device);
     if (g.rc) return g.rc;
-    return upload_host(e->st[slot], a, b, e->stream);
+    // (the residues go up now -- the caller's buffers are its own again when this returns --; alphabet, ids and table are
+    // built by the launch's binding kernels, for all slots at once)
+    psa_stripe* s = e->st[slot];
+    HIP_TRY(hipMemcpyAsync(s->a_dev, a, (size_t)n, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(s->b_dev, b, (size_t)m, hipMemcpyHostToDevice, e->stream));
+    s->src_a = s->src_b = nullptr;
+    s->rebind = true;
+    return PSA_OK;
 }
 
 int psa_many_set_pair_dev(psa_many* e, int slot, const uint8_t* a_dev, int64_t n, const uint8_t* b_dev, int64_t m) {
@@ -1397,12 +1417,12 @@ int psa_many_set_pair_dev(psa_many* e, int slot, const uint8_t* a_dev, int64_t n
     if ((n > 0 && !a_dev) || (m > 0 && !b_dev)) return fail(PSA_E_ARG, "psa_many_set_pair_dev: null sequence");
     if (int rc = many_bind(e, slot, n, m)) return rc;
     if (e->bound[slot] != 1) return PSA_OK;
-    DeviceGuard g(e->device);
-    if (g.rc) return g.rc;
+    // nothing is queued here: the next launch's binding kernels copy the residues into the slot's buffers and encode
+    // them, all slots in three launches (a dozen stream operations per slot before: 2.7 ms for 20 slots)
     psa_stripe* s = e->st[slot];
-    HIP_TRY(hipMemcpyAsync(s->a_dev, a_dev, (size_t)n, hipMemcpyDeviceToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(s->b_dev, b_dev, (size_t)m, hipMemcpyDeviceToDevice, e->stream));
-    return rebuild_tables(s, e->stream, -1);
+    s->src_a = a_dev; s->src_b = b_dev;
+    s->rebind = true;
+    return PSA_OK;
 }
 
 int psa_many_clear_slot(psa_many* e, int slot) {
@@ -1428,33 +1448,39 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
     if (after && after != e && after->launched) HIP_TRY(hipStreamWaitEvent(st, after->ev[1], 0));
     const bool with_codes = (e->flags & PSA_F_TRACEBACK) != 0;
     psa::FillArgs2 jobs[psa::kMaxJobs];
-    int slot_of[psa::kMaxJobs];
     unsigned groups[psa::kMaxJobs];
     int nj = 0;
     unsigned total = 0, rounds = 0;
+    // Binding: everything the slots need before the fill -- residues of re-bound pairs into the slots' own buffers, their
+    // alphabet, ids and table, and the zeroing of rings and control blocks -- in three launches over all slots.
+    psa::BindBatch bb;
+    memset(&bb, 0, sizeof bb);
+    const char* force_fill = getenv("PSA_FILL_KERNEL");
+    const bool generic = force_fill && !strcmp(force_fill, "v1");
     for (int k = 0; k < e->slots; ++k) {
         if (e->bound[k] != 1) continue;
         psa_stripe* s = e->st[k];
-        // A pair bound from DEVICE memory: how many distinct residues A has comes back with the table kernels, which
-        // may sit behind another engine's fill for milliseconds.  The launch does not wait for them (the host would
-        // then queue this fill only when the other has drained): the table kernel takes any alphabet (a table row
-        // per distinct byte value, kMaxSym = 256), so the count only matters when the generic kernel is forced.
-        if (s->nsym_pending) {
-            const char* force = getenv("PSA_FILL_KERNEL");
-            if (force && !strcmp(force, "v1")) { if (int rc = settle_tables(s)) return rc; }
-            else s->use_v2 = true;
-        }
-        if (!s->use_v2) {   // the generic kernel (PSA_FILL_KERNEL=v1): a launch of its own
-            if (int rc = fill_rows_impl(s, 0, s->n, nullptr, nullptr, st, FillOpts())) return rc;
-            continue;
-        }
+        psa::BindJob& bj = bb.job[bb.njobs++];
+        bj.a = s->a_dev; bj.b = s->b_dev; bj.n = s->n; bj.W = s->W; bj.pitch = s->tab_pitch;
+        bj.alpha = (unsigned*)s->alpha; bj.ids = s->a_ids; bj.eqtab = s->eqtab;
+        if (s->rebind) { bj.src_a = s->src_a; bj.src_b = s->src_b; bj.tables = 1; s->rebind = false; }
+        s->nsym_pending = false;
+        s->use_v2 = !generic;   // (the table kernel takes any byte alphabet: a table row per distinct residue, kMaxSym = 256)
+        if (generic) continue;  // the generic kernel (PSA_FILL_KERNEL=v1): launches of its own below, with their own memsets
         bool wc = false;
-        if (int rc = prepare_fill(s, 0, s->n, nullptr, nullptr, st, FillOpts(), &jobs[nj], &wc)) return rc;
+        FillOpts fo;
+        fo.clear_into = &bj;
+        if (int rc = prepare_fill(s, 0, s->n, nullptr, nullptr, st, fo, &jobs[nj], &wc)) return rc;
         groups[nj] = groups_of(jobs[nj]);
         total += groups[nj];
         rounds = std::max(rounds, groups[nj]);
-        slot_of[nj++] = k;
+        ++nj;
     }
+    HIP_TRY(psa::launch_bind(bb, st));
+    if (generic)
+        for (int k = 0; k < e->slots; ++k)
+            if (e->bound[k] == 1)
+                if (int rc = fill_rows_impl(e->st[k], 0, e->st[k]->n, nullptr, nullptr, st, FillOpts())) return rc;
     if (nj > 0) {
         const uint32_t* order_dev = nullptr;
         if (nj > 1) {   // round-robin over the jobs that still have groups left
@@ -1507,17 +1533,25 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         }
     }
     HIP_TRY(hipEventRecord(e->ev[2], st));
+    psa::CollectBatch cb;
+    memset(&cb, 0, sizeof cb);
+    cb.out = e->d_res;
     for (int k = 0; k < e->slots; ++k) {
         if (e->bound[k] != 1) continue;
         psa_stripe* s = e->st[k];
-        HIP_TRY(hipMemcpyAsync(e->h_triple + 4 * k, s->small + kFinalWord, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(e->h_abort + k, s->ctrl + kAbortWord, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        if (with_codes) {
-            HIP_TRY(hipMemcpyAsync(e->h_state + 16 * k, s->tb_state, sizeof(int64_t) * 12, hipMemcpyDeviceToHost, st));
-            const size_t cnt = (size_t)(s->n + s->W + 2);   // (the walk's length is not known on the host yet: all it can be)
-            HIP_TRY(hipMemcpyAsync(e->h_ai[k], s->tb_ai, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(e->h_bj[k], s->tb_bj, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
-        }
+        psa::CollectJob& cj = cb.job[cb.njobs++];
+        cj.state = with_codes ? s->tb_state : nullptr; cj.triple = s->small + kFinalWord; cj.abort_flag = s->ctrl + kAbortWord; cj.slot = k;
+    }
+    if (cb.njobs > 0) {
+        HIP_TRY(psa::launch_collect(cb, st));
+        HIP_TRY(hipMemcpyAsync(e->h_res, e->d_res, sizeof(int32_t) * psa::kResultWords * (size_t)e->slots, hipMemcpyDeviceToHost, st));
+    }
+    for (int k = 0; k < e->slots && with_codes; ++k) {
+        if (e->bound[k] != 1) continue;
+        psa_stripe* s = e->st[k];
+        const size_t cnt = (size_t)(s->n + s->W + 2);   // (the walk's length is not known on the host yet: all it can be)
+        HIP_TRY(hipMemcpyAsync(e->h_ai[k], s->tb_ai, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(e->h_bj[k], s->tb_bj, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(e->ev[3], st));
     e->launched = true;
@@ -1544,8 +1578,9 @@ int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_ou
     if (n == 0) { t[0] = -1; t[1] = 0; t[2] = (int32_t)-(2 + m); }
     else if (m == 0) { t[0] = -1; t[1] = (int32_t)-(2 + n); t[2] = -1; }
     else {
-        if (e->h_abort[slot]) return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired (slot %d)", slot);
-        memcpy(t, e->h_triple + 4 * slot, sizeof t);
+        const int32_t* r = e->h_res + (size_t)psa::kResultWords * slot;
+        if (r[27]) return fail(PSA_E_KERNEL, "fill kernel: a strip's wait for the strip above expired (slot %d)", slot);
+        memcpy(t, r + 24, sizeof t);
     }
     pick3(t, score_out);
     if (triple_out) memcpy(triple_out, t, sizeof t);
@@ -1553,7 +1588,8 @@ int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_ou
     if (!len_out) return fail(PSA_E_ARG, "psa_many_result: len_out is null");
     int64_t len = 0;
     if (n > 0 && m > 0) {
-        const int64_t* stt = e->h_state + 16 * slot;
+        int64_t stt[12];
+        memcpy(stt, e->h_res + (size_t)psa::kResultWords * slot, sizeof stt);
         if (stt[5] == 2) return fail(PSA_E_KERNEL, "traceback: winner codes failed the decode check (slot %d)", slot);
         if (stt[5] == 3) return fail(PSA_E_KERNEL, "traceback: the walk waited in vain for a code tile (slot %d)", slot);
         if (stt[5]) return fail(PSA_E_KERNEL, "traceback: device buffer overflow (slot %d)", slot);
@@ -1576,6 +1612,16 @@ int psa_many_last_ms(psa_many* e, float* fill_ms_out, float* walk_ms_out) {
     return PSA_OK;
 }
 
+int psa_many_fill_ms_since(psa_many* e, void* ref_event, float* begin_ms_out, float* end_ms_out) {
+    if (!e || !ref_event) return fail(PSA_E_ARG, "psa_many_fill_ms_since: null argument");
+    if (e->launched) if (int rc = psa_many_wait(e)) return rc;
+    DeviceGuard g(e->device);
+    if (g.rc) return g.rc;
+    if (begin_ms_out) HIP_TRY(hipEventElapsedTime(begin_ms_out, (hipEvent_t)ref_event, e->ev[0]));
+    if (end_ms_out) HIP_TRY(hipEventElapsedTime(end_ms_out, (hipEvent_t)ref_event, e->ev[1]));
+    return PSA_OK;
+}
+
 int64_t psa_many_code_bytes(const psa_many* e, int slot) {
     return (e && slot >= 0 && slot < e->slots && e->bound[slot] == 1) ? (int64_t)e->st[slot]->code_bytes : 0;
 }
@@ -1595,23 +1641,28 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
         n_cap = std::max(n_cap, n[k]); m_cap = std::max(m_cap, m[k]);
         if (want_al) { ai_out[k] = bj_out[k] = nullptr; len_out[k] = 0; }
     }
-    // Engines and slots.  A fill launch costs about 4 ms beyond 1.75 ms per 2^16 pair (its ramp and drain), so launches
-    // of up to 16 pairs (what a launch's argument block holds); three engines taking turns where the device memory
-    // holds them -- each fill is then queued while the one before it runs and takes over the chip as that one drains,
-    // and nobody waits for an engine's walks, which get their turn at the next drain --, else two, each fill after the
-    // other's end (the walks and copies of one beside the fill of the other).  70 % of the free memory at most.
+    // Engines and slots.  A fill launch costs about 4 ms beyond 1.75 ms per 2^16 pair (its ramp and drain), so as few
+    // launches as the argument block allows (kMaxJobs pairs each), of equal size.  Three engines taking turns where
+    // there are that many launches and the device memory holds them -- each fill is then queued while the one before it
+    // runs and takes over the chip as that one drains, and nobody waits for an engine's walks, which get their turn at
+    // the next drain --, else two, each fill after the other's end (the walks and copies of one beside the fill of the
+    // other); slots before engines (20 + 20 rather than 3 x 13).  70 % of the free memory at most.
     psa_release_cache();
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     const double per_slot = (want_al ? (double)n_cap * (double)m_cap * 1.05 : 0.0) + 64.0 * (double)(n_cap + m_cap) + (1 << 20);
-    const double budget = 0.7 * (double)free_b;
-    int E = 3;
-    int slots = (int)std::min<double>(16.0, budget / (3.0 * per_slot));
-    if (slots < 8 || npairs <= 2 * (int64_t)slots) {   // (few pairs, or little memory: two engines with more slots each)
-        E = 2;
-        slots = (int)std::min<double>(16.0, budget / (2.0 * per_slot));
+    const int64_t fit = (int64_t)std::min<double>(1e6, 0.7 * (double)free_b / per_slot);   // slots the memory holds
+    int slots = (int)std::min<int64_t>(std::min<int64_t>(psa::kMaxJobs, fit), npairs);
+    int E = 1;
+    if (slots >= 1) {
+        int64_t launches = (npairs + slots - 1) / slots;
+        if (launches > 1 && fit < 2 * (int64_t)slots) {   // more than one launch: two engines at least, so that walks overlap fills
+            slots = (int)std::max<int64_t>(1, fit / 2);
+            launches = (npairs + slots - 1) / slots;
+        }
+        E = (int)std::min<int64_t>(std::min<int64_t>(3, launches), std::max<int64_t>(1, fit / slots));
+        slots = (int)((npairs + launches - 1) / launches);
     }
-    slots = (int)std::min<int64_t>(slots, (npairs + E - 1) / E);
     if (slots < 1) {
         // not even one pair per engine fits with its codes: one at a time through psa_align (linear space if need be)
         for (int64_t k = 0; k < npairs; ++k) {
@@ -1647,7 +1698,7 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
             if (k < npairs) { rc = psa_many_set_pair(eng[turn], sl, a[k], n[k], b[k], m[k]); held[turn].push_back(k); }
             else rc = psa_many_clear_slot(eng[turn], sl);
         }
-        if (rc == PSA_OK) rc = (E == 3) ? psa_many_launch(eng[turn]) : psa_many_launch_after(eng[turn], eng[turn ^ 1]);
+        if (rc == PSA_OK) rc = (E == 2) ? psa_many_launch_after(eng[turn], eng[turn ^ 1]) : psa_many_launch(eng[turn]);
     }
     for (int x = 0; x < E && rc == PSA_OK; ++x) if (!held[(turn + x) % E].empty()) rc = collect((turn + x) % E);
     for (int x = 0; x < E; ++x) free_many(eng[x]);

@@ -25,6 +25,11 @@ hipError_t launch_tables(const uint8_t* a_dev, int64_t n, const uint8_t* b_dev, 
 constexpr size_t kAlphaBytes = 256 * 4 + 16 + 256 + 256;   // present[256] (u32) | meta[4] (u32) | map[256] | inv[256]
 inline unsigned* alpha_meta(uint8_t* alpha) { return (unsigned*)alpha + 256; }
 
+// the same for all slots of a multi-pair launch in three launches, with the zeroing the fill needs (BindBatch), and the
+// slots' results gathered for one copy to the host (CollectBatch)
+hipError_t launch_bind(const BindBatch& bb, hipStream_t st);
+hipError_t launch_collect(const CollectBatch& cb, hipStream_t st);
+
 hipError_t launch_edge_post(const int32_t* packed, int64_t r0, int64_t rows, int64_t n, int32_t* plane, uint32_t* flags, hipStream_t st);
 hipError_t launch_edge_take(const int32_t* plane, const uint32_t* done, int64_t r0, int64_t rows, int64_t n, int32_t* packed,
                             unsigned* abort_flag, hipStream_t st);

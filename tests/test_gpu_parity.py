@@ -209,7 +209,7 @@ def _columns_md5(res):
 
 
 def test_dense_launch_at_bench_shape_distinct_pairs(golden_dir):
-    """The kernel bench.py times -- fill_strips_v2_dense: ONE launch over 16 pairs of 2^16 x 2^16, 1 024 strips each, two
+    """The kernel bench.py times -- fill_strips_v2_dense: ONE launch over 20 pairs of 2^16 x 2^16 (all an argument block holds), 1 024 strips each, two
     workgroups per CU, ring wrap-around -- at the bench's own shape with a DIFFERENT pair in every slot, two slots of
     other sizes (titin; 50 000 x 65 536 / 65 536 x 40 000), two launches back to back on two engines as bench.py
     does.  Every slot: score, alignment length and the md5 of all its columns against the committed restatement-only
@@ -219,18 +219,19 @@ def test_dense_launch_at_bench_shape_distinct_pairs(golden_dir):
     n = m = 1 << 16
     ta = np.frombuffer(psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "titin_homo(50).fasta")), np.uint8)
     tb = np.frombuffer(psa_amd.read_fasta(os.path.join(golden_dir, "sequences", "titin_mus.fasta")), np.uint8)
-    engines = [psa_amd.Many(16, n, m, traceback=True) for _ in range(2)]
+    S = 20
+    engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(2)]
     layouts = []
     for x in range(2):
         lay = []
-        for sl in range(16):
-            if sl == 14:
+        for sl in range(S):
+            if sl == S - 2:
                 lay.append(("titin", ta, tb))
-            elif sl == 15:
+            elif sl == S - 1:
                 key = (1, 50000, m) if x == 0 else (2, n, 40000)
                 lay.append((key,) + _bench_pair(*key))
             else:
-                slot = (sl + 7 * x) % 14            # (the second engine holds the pairs in other slots)
+                slot = (sl + 7 * x) % (S - 2)       # (the second engine holds the pairs in other slots)
                 lay.append(((slot, n, m),) + _bench_pair(slot))
         layouts.append(lay)
     for x, eng in enumerate(engines):
@@ -248,7 +249,7 @@ def test_dense_launch_at_bench_shape_distinct_pairs(golden_dir):
                 continue
             g = gold[key]
             assert (res.score, len(res.ai), _columns_md5(res)) == (g["score"], g["alignment_len"], g["columns_md5"]), (x, sl, key)
-            if (x, sl) in ((0, 0), (0, 15), (1, 3), (1, 15)):
+            if (x, sl) in ((0, 0), (0, S - 1), (1, 3), (1, S - 1)):
                 live[(x, sl)] = (a, b, res)
     for e in engines:
         e.close()
