@@ -3,8 +3,11 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete alignment of the workload pair: DP fill with winner codes written to HBM,
-final pick, traceback walk, prefix fix-up (what run() does in simple.cpp:261-294).  Inputs are
+One "step" = one pass of the hot path over one BATCH of the synthetic input: --slots (20) DISTINCT pairs of the
+workload size, each aligned completely -- DP fill with winner codes written to HBM, final pick, traceback walk,
+prefix fix-up (what run() does in simple.cpp:261-294, once per pair) --, the batch being ONE fill launch and ONE launch
+of the walks.  (Until round 3 a step was one alignment; with the driver's --steps 20 the timed region was then a single
+launch, its ramp, drain and last walk in full view and no steady state: now it is 20 launches, 400 alignments.)  Inputs are
 resident in HBM before the timed region.  N = 1: the synthetic 2^16 x 2^16 protein pair of BASELINE
 config 4 on one GPU.  One pair alone cannot fill the GPU (its anti-diagonal dependency chain is
 n + m steps long whatever the hardware), so the job is what psa_align_many does: ONE host thread
@@ -53,8 +56,8 @@ PROFILE_DIR = os.path.join("profiles", "r3")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=240)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=12, help="batches (fill launches of --slots alignments each) in the timed region")
+    ap.add_argument("--warmup", type=int, default=3, help="untimed batches before it (at least one per engine is run)")
     ap.add_argument("--log2n", type=int, default=16, help="synthetic pair is 2^k x 2^k")
     ap.add_argument("--chunk-rows", type=int, default=0, help="rows per inter-GPU hand-off (N > 1, stripes); 0 = from the stripe width")
     ap.add_argument("--slots", type=int, default=MAX_SLOTS, help="pairs per launch (1..%d); up to three engines take turns" % MAX_SLOTS)
@@ -294,8 +297,8 @@ def single_gpu(args):
     free_b, _total_b = torch.cuda.mem_get_info()
     slot_b = float(n) * m * 1.02 + (64 << 20)
     fit = int(0.95 * free_b / slot_b)
-    S = max(1, min(S, fit // 2 if args.steps > S else fit))
-    batches = plan_batches(args.steps, S)
+    S = max(1, min(S, fit // 2 if args.steps > 1 else fit))
+    batches = [S] * args.steps
     E = 2 if args.serial_fills else max(1, min(3, args.engines))
     E = max(1, min(E, len(batches), fit // S))
     pairs = slot_pairs(psa_amd, torch, k, S)
@@ -304,11 +307,11 @@ def single_gpu(args):
     engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(E)]
     serial = args.serial_fills and E > 1
 
-    # The timed region is `steps` alignments as the fewest launches of equal size (--steps 20: ONE launch of 20 on one
-    # engine; the default 240: 12 launches of 20, three engines taking turns).  Warm-up: at least one launch of that size on EACH engine (its
-    # ticket order, tables and code pages are then in place), more if --warmup asks for more alignments than that.
+    # The timed region is `steps` batches = launches of S alignments each (--steps 20: 400 alignments; the default 12:
+    # 240), three engines taking turns.  Warm-up: at least one launch on EACH engine (its ticket order, tables and code
+    # pages are then in place), more if --warmup asks for more batches than that.
     per_launch = max(batches)
-    warm_launches = max(E, -(-args.warmup // per_launch))
+    warm_launches = max(E, args.warmup)
     warm_launches += (-warm_launches) % E
     throughput_job(engines, pairs, n, m, [per_launch] * warm_launches, serial)
     torch.cuda.synchronize()
@@ -332,7 +335,8 @@ def single_gpu(args):
         dt = float(dtt.item())
     # every alignment of the timed region against the precomputed list (or, for sizes without goldens, against the
     # other launches' result for the same slot)
-    assert len(res) == args.steps, (len(res), args.steps)
+    aligned = args.steps * S
+    assert len(res) == aligned, (len(res), aligned)
     by_slot = {}
     for sl, sc_, ln_ in res:
         by_slot.setdefault(sl, set()).add((sc_, ln_))
@@ -344,8 +348,9 @@ def single_gpu(args):
             checked += 1
     sc, ln = next(iter(by_slot[0]))
     cells1 = float(n) * m
-    cells = cells1 * world                # per step: one alignment on every rank
+    cells = cells1 * world                # per alignment of the count below: one on every rank
     ms_step = dt / args.steps * 1e3
+    ms_alignment = dt / aligned * 1e3
     code_bytes = engines[0].code_bytes(0)
     for e in engines:
         e.close()
@@ -371,24 +376,25 @@ def single_gpu(args):
         fill_ms_note = ("HIP events around the fill launch on the engine's stream, every launch of the timed region"
                         + ("; the other engine's walks (one wavefront per pair) run beside it" if E > 1 else ""))
     achieved = per_launch_pairs * cells1 * OPS_PER_CELL_CODES / (fill_ms * 1e-3) / 1e12
-    aggregate = cells1 * OPS_PER_CELL_CODES * args.steps / dt / 1e12
+    aggregate = cells1 * OPS_PER_CELL_CODES * aligned / dt / 1e12
     grid = per_launch_pairs * ((n + 255) // 256)
     traffic, traffic_src = pmc_traffic("<true>(psa::FillBatch)", grid * 256)
 
     out = {
         "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of 2^%d x 2^%d pairs" % (k, k),
-        "value": cells / (dt / args.steps) / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
+        "value": cells * aligned / dt / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "ms_per_alignment": ms_alignment, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": "synthetic iid 20-letter protein pair 2^%d x 2^%d (mt19937_64 seeds 0xA/0xB0000000+%d), "
                                "fill with one-byte winner codes in HBM + traceback walk + prefix fix-up; one step = one "
-                               "complete alignment per GPU; ONE host thread, %d engine%s, %d DISTINCT pairs per "
+                               "batch of %d complete alignments per GPU (one fill launch + one launch of the walks); ONE host thread, %d engine%s, %d DISTINCT pairs per "
                                "fill launch and per walk launch (slot s: seeds +0x100*s; psa_many / psa_align_many); no "
-                               "inter-GPU communication" % (k, k, k, E, " (one launch holds the whole timed region)" if E == 1 else "s taking turns", per_launch),
+                               "inter-GPU communication" % (k, k, k, S, E, " (one launch holds the whole timed region)" if E == 1 else "s taking turns", per_launch),
+                   "alignments_timed": aligned, "alignments_per_step": S,
                    "n": n, "m": m, "score": int(sc), "alignment_len": int(ln), "stripes": 1, "pairs_per_launch": per_launch,
                    "launch_sizes_timed": batches, "engine_slots": S, "engines": E,
                    "warmup_alignments_run": per_launch * warm_launches,
-                   "warmup_note": "--warmup %d asked; run: %d launches of %d (one full launch on EACH engine at least)"
+                   "warmup_note": "--warmup %d batches asked; run: %d launches of %d (one full launch on EACH engine at least)"
                                   % (args.warmup, warm_launches, per_launch),
                    "results_checked": "%d of %d slots against tests/golden/oracle_only.json (score, alignment length); every "
                                       "slot equal across launches" % (checked, len(by_slot)),
