@@ -12,15 +12,19 @@ all: $(LIB) simple oracle
 # side by side; the fill kernels with and without winner codes are the two long ones).
 CS      := $(PKG)/csrc
 OBJDIR  := build/obj
-OBJS    := $(addprefix $(OBJDIR)/,psa_hip.o psa_fill_codes.o psa_fill_score.o psa_trace.o psa_batch.o)
+OBJS    := $(addprefix $(OBJDIR)/,psa_hip.o psa_fill_codes.o psa_fill_score.o psa_fill_pk.o psa_trace.o psa_batch.o)
 COMMON  := $(CS)/psa_args.hip.h $(CS)/psa_device.hip.h $(CS)/psa_launch.h $(CS)/psa_host.h include/psa.h
 FILLH   := $(CS)/psa_fill_tu.hip.h $(CS)/psa_fill_v2.hip.h $(CS)/psa_fill_v1.hip.h
 
 $(OBJDIR)/psa_hip.o: $(CS)/psa_hip.hip $(COMMON)
 $(OBJDIR)/psa_fill_codes.o: $(CS)/psa_fill_codes.hip $(FILLH) $(COMMON)
 $(OBJDIR)/psa_fill_score.o: $(CS)/psa_fill_score.hip $(FILLH) $(CS)/psa_fill_aux.hip.h $(COMMON)
+$(OBJDIR)/psa_fill_pk.o: $(CS)/psa_fill_pk.hip $(CS)/psa_fill_pk.hip.h $(FILLH) $(COMMON)
 $(OBJDIR)/psa_trace.o: $(CS)/psa_trace.hip $(CS)/psa_trace1.hip.h $(CS)/psa_trace2.hip.h $(COMMON)
 $(OBJDIR)/psa_batch.o: $(CS)/psa_batch.hip $(CS)/psa_batch.hip.h $(COMMON)
+
+PKWAVES ?= 2
+$(OBJDIR)/psa_fill_pk.o: HIPFLAGS += -DPSA_PK_WAVES=$(PKWAVES)
 
 $(OBJDIR)/%.o:
 	mkdir -p $(OBJDIR)

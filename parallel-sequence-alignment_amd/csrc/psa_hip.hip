@@ -1481,7 +1481,67 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         for (int k = 0; k < e->slots; ++k)
             if (e->bound[k] == 1)
                 if (int rc = fill_rows_impl(e->st[k], 0, e->st[k]->n, nullptr, nullptr, st, FillOpts())) return rc;
-    if (nj > 0) {
+    // Couples for the packed kernel (two pairs per lane, psa_fill_pk.hip.h): pairs of the same size, two by two; whatever
+    // is left over goes through the one-pair kernel in launches of its own.  PSA_FILL_PK=0: everything as one launch of
+    // the int32 kernel (the cross-check).
+    int pk_of[psa::kMaxJobs], npk = 0, rest_of[psa::kMaxJobs], nrest = 0;
+    {
+        const char* pkv = getenv("PSA_FILL_PK");   // (read at every launch: the tests switch it)
+        const bool pk_ok = !(pkv && pkv[0] == '0');
+        if (pk_ok && with_codes && nj >= 2) {
+            int idx[psa::kMaxJobs];
+            for (int j = 0; j < nj; ++j) idx[j] = j;
+            std::stable_sort(idx, idx + nj, [&](int x, int y) {
+                return jobs[x].base.n != jobs[y].base.n ? jobs[x].base.n < jobs[y].base.n : jobs[x].base.W < jobs[y].base.W;
+            });
+            for (int j = 0; j < nj;) {
+                const psa::FillArgs &fx = jobs[idx[j]].base;
+                if (j + 1 < nj && fx.n == jobs[idx[j + 1]].base.n && fx.W == jobs[idx[j + 1]].base.W && fx.W >= 256 && fx.n >= 64 &&
+                    fx.W < (1 << 24)) {
+                    pk_of[npk++] = idx[j]; pk_of[npk++] = idx[j + 1];
+                    j += 2;
+                } else rest_of[nrest++] = idx[j++];
+            }
+        }
+    }
+    if (npk > 0) {
+        const int nc = npk / 2;
+        psa::FillBatch fb;
+        memset(&fb, 0, sizeof fb);
+        unsigned cgroups[psa::kMaxJobs], ctotal = 0, crounds = 0;
+        for (int x = 0; x < npk; ++x) fb.job[x] = jobs[pk_of[x]];
+        for (int cidx = 0; cidx < nc; ++cidx) {
+            cgroups[cidx] = groups[pk_of[2 * cidx]];
+            ctotal += cgroups[cidx];
+            crounds = std::max(crounds, cgroups[cidx]);
+        }
+        std::vector<unsigned> sig(cgroups, cgroups + nc);
+        sig.push_back(0x504b0000u);   // (an order over couples, not over jobs)
+        if (sig != e->order_sig) {
+            std::vector<uint32_t> order;
+            order.reserve(ctotal);
+            for (unsigned r = 0; r < crounds; ++r)
+                for (int cidx = 0; cidx < nc; ++cidx)
+                    if (r < cgroups[cidx]) order.push_back(((uint32_t)cidx << psa::kOrderJobShift) | r);
+            if (e->order_cap < order.size()) {
+                hipFree(e->order);
+                e->order = nullptr; e->order_cap = 0;
+                HIP_TRY(hipMalloc(&e->order, sizeof(uint32_t) * order.size()));
+                e->order_cap = order.size();
+            }
+            HIP_TRY(hipMemcpyAsync(e->order, order.data(), sizeof(uint32_t) * order.size(), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            e->order_sig = sig;
+        }
+        fb.njobs = npk; fb.order = e->order; fb.ticket = e->ticket;
+        HIP_TRY(hipMemsetAsync(e->ticket, 0, 256, st));
+        HIP_TRY(hipEventRecord(e->ev[0], st));
+        HIP_TRY(psa::launch_fill_pk(fb, ctotal, st));
+        for (int x = 0; x < nrest; ++x) {
+            const psa::FillArgs2& fj = jobs[rest_of[x]];
+            if (int rc = launch_fill_v2(&fj, 1, nullptr, groups[rest_of[x]], fj.base.ticket, with_codes, psa::kKeepoutAloneBytes, st, false)) return rc;
+        }
+    } else if (nj > 0) {
         const uint32_t* order_dev = nullptr;
         if (nj > 1) {   // round-robin over the jobs that still have groups left
             const std::vector<unsigned> sig(groups, groups + nj);
