@@ -44,6 +44,9 @@ VALU_PEAK_TOPS = 39.3216      # 256 CU x 64 int32 lanes/clk x 2.4 GHz (tools/val
 # SURVEY's are kept beside them (frac_at_survey_ops) for comparison with round 1.
 OPS_PER_CELL_CODES = 11
 OPS_PER_CELL_SCORE = 8
+OPS_PER_CELL_CODES_PK = 13    # the packed fill (psa_fill_pk.hip.h): 13 instructions per step of TWO cells = 13 sixteen-bit lane operations
+                              # per cell (2 DPP moves, 1 perm for the two substitution bytes, 3 adds, 4 max, 2 mad + 1 perm for the
+                              # code bytes), priced against PK_PEAK_TOPS
 OPS_PER_CELL_BATCH = 10       # batch kernel, int32 path: compares residues itself (v_cmp + v_cndmask) instead of a table byte
 OPS_PER_CELL_BATCH_PK = 12    # packed path: 12 instructions per step of TWO cells = 12 sixteen-bit lane operations per cell,
 MAX_SLOTS = 20   # pairs per fill launch: what the kernel's 4 KB argument block holds (psa_args.hip.h, kMaxJobs)
@@ -375,16 +378,25 @@ def single_gpu(args):
         fill_ms = sum(full) / len(full)
         fill_ms_note = ("HIP events around the fill launch on the engine's stream, every launch of the timed region"
                         + ("; the other engine's walks (one wavefront per pair) run beside it" if E > 1 else ""))
-    achieved = per_launch_pairs * cells1 * OPS_PER_CELL_CODES / (fill_ms * 1e-3) / 1e12
-    aggregate = cells1 * OPS_PER_CELL_CODES * aligned / dt / 1e12
-    grid = per_launch_pairs * ((n + 255) // 256)
-    traffic, traffic_src = pmc_traffic("<true>(psa::FillBatch)", grid * 256)
-
+    # Which fill kernel the launches took: couples of pairs through the packed 16-bit kernel (two pairs per lane) unless
+    # PSA_FILL_PK=0 or one pair per launch; its roofline is the packed one (two 16-bit lane operations per lane and clock).
+    packed = per_launch_pairs >= 2 and per_launch_pairs % 2 == 0 and os.environ.get("PSA_FILL_PK", "1") != "0"
+    ops_cell = OPS_PER_CELL_CODES_PK if packed else OPS_PER_CELL_CODES
+    peak = PK_PEAK_TOPS if packed else VALU_PEAK_TOPS
+    achieved = per_launch_pairs * cells1 * ops_cell / (fill_ms * 1e-3) / 1e12
+    aggregate = cells1 * ops_cell * aligned / dt / 1e12
+    if packed:
+        kname, kpat = "fill_strips_pk", "fill_strips_pk"
+        grid = (per_launch_pairs // 2) * ((n + 255) // 256)
+    else:
+        kname, kpat = ("fill_strips_v2_dense<true>" if per_launch_pairs > 1 else "fill_strips_v2<true>"), "<true>(psa::FillBatch)"
+        grid = per_launch_pairs * ((n + 255) // 256)
+    traffic, traffic_src = pmc_traffic(kpat, grid * 256)
     out = {
         "metric": "GCUPS (cell updates/s), full alignment (fill + traceback) of 2^%d x 2^%d pairs" % (k, k),
         "value": cells * aligned / dt / 1e9, "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_step, "ms_per_alignment": ms_alignment, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "int16" if packed else "int32", "data": "synthetic",
         "config": {"workload": "synthetic iid 20-letter protein pair 2^%d x 2^%d (mt19937_64 seeds 0xA/0xB0000000+%d), "
                                "fill with one-byte winner codes in HBM + traceback walk + prefix fix-up; one step = one "
                                "batch of %d complete alignments per GPU (one fill launch + one launch of the walks); ONE host thread, %d engine%s, %d DISTINCT pairs per "
@@ -401,19 +413,28 @@ def single_gpu(args):
                    "fill_launches_overlap": not serial and E > 1, "host_threads": 1,
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),
                    "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
-        "roofline": {"bound": "valu", "kernel": ("fill_strips_v2_dense<true>: ONE launch filling %d pairs (winner codes on), two wavefronts per SIMD" % per_launch_pairs)
-                               if per_launch_pairs > 1 else "fill_strips_v2<true>: one pair per launch (winner codes on), one wavefront per SIMD",
-                     "achieved": achieved, "peak": VALU_PEAK_TOPS, "unit": "Tint32op/s", "frac": achieved / VALU_PEAK_TOPS,
-                     "ops_per_cell": OPS_PER_CELL_CODES, "cells_per_launch": per_launch_pairs * cells1,
-                     "frac_at_survey_ops": achieved / VALU_PEAK_TOPS * SURVEY_OPS_CODES / OPS_PER_CELL_CODES,
-                     "ops_note": "11 = 8 for the recurrence + 3 for the one-byte winner code; SURVEY 8d's 25 priced three "
-                                 "compares per aggregate, which this kernel does not do (frac_at_survey_ops keeps that scale)",
-                     "valu_insts_per_cell_executed": pmc_valu_per_cell("<true>(psa::FillBatch)", grid * 256, per_launch_pairs * cells1),
+        "roofline": {"bound": "valu",
+                     "kernel": ("%s: ONE launch filling %d pairs (winner codes on), %s" % (
+                         kname, per_launch_pairs, "two pairs per lane in packed 16-bit halves, two wavefronts per SIMD" if packed
+                         else "two wavefronts per SIMD")) if per_launch_pairs > 1
+                     else "fill_strips_v2<true>: one pair per launch (winner codes on), one wavefront per SIMD",
+                     "achieved": achieved, "peak": peak, "unit": "T 16-bit lane operations / s" if packed else "Tint32op/s",
+                     "frac": achieved / peak,
+                     "ops_per_cell": ops_cell, "cells_per_launch": per_launch_pairs * cells1,
+                     "frac_of_int32_peak_at_11_ops": per_launch_pairs * cells1 * OPS_PER_CELL_CODES / (fill_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                     "frac_at_survey_ops": per_launch_pairs * cells1 * SURVEY_OPS_CODES / (fill_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                     "ops_note": ("packed kernel: 13 instructions per step for the cells of TWO pairs (psa_fill_pk.hip.h), each a pair of "
+                                  "16-bit lane operations, against a peak of 2 x 39.3 T such operations / s; "
+                                  "frac_of_int32_peak_at_11_ops keeps the scale of the int32 kernel (11 = 8 for the recurrence + 3 for "
+                                  "the one-byte winner code) and of earlier rounds, frac_at_survey_ops SURVEY 8d's 25") if packed else
+                                 ("11 = 8 for the recurrence + 3 for the one-byte winner code; SURVEY 8d's 25 priced three "
+                                  "compares per aggregate, which this kernel does not do (frac_at_survey_ops keeps that scale)"),
+                     "valu_insts_per_cell_executed": pmc_valu_per_cell(kpat, grid * 256, per_launch_pairs * cells1),
                      "kernel_ms": fill_ms, "launches_timed": len(full),
                      "kernel_ms_note": fill_ms_note,
                      "fill_end_ms": [round(t, 3) for t in ends], "fill_start_to_end_ms": [round(f, 3) for f, _ in fills],
                      "fill_gcups": per_launch_pairs * cells1 / (fill_ms * 1e-3) / 1e9,
-                     "aggregate_achieved": aggregate, "aggregate_frac": aggregate / VALU_PEAK_TOPS,
+                     "aggregate_achieved": aggregate, "aggregate_frac": aggregate / peak,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (separate --pmc passes)",
                      "traffic_source": traffic_src,
                      "code_stream": {"bytes_per_launch": code_bytes * per_launch_pairs,
@@ -499,7 +520,7 @@ def single_gpu(args):
         al.close()
         ms_al = sum(fa[1:]) / len(fa[1:])
         out["roofline"]["alone"] = {"kernel_ms": ms_al, "pairs": per_launch,
-                                    "frac": per_launch * cells1 * OPS_PER_CELL_CODES / (ms_al * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                    "frac": per_launch * cells1 * ops_cell / (ms_al * 1e-3) / 1e12 / peak,
                                     "note": "one launch with the chip to itself, start to end (ramp and drain included)"}
     out["one_pair_alone"] = {"ms": lat_ms, "gcups": cells1 / (lat_ms * 1e-3) / 1e9, "fill_ms": fill1, "traceback_ms": walk1}
     if stripes_info is not None:

@@ -258,6 +258,53 @@ def test_dense_launch_at_bench_shape_distinct_pairs(golden_dir):
         assert res.score == sc and np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (x, sl)
 
 
+def test_packed_fill_couples_match_oracle(monkeypatch):
+    """fill_strips_pk (psa_fill_pk.hip.h): the engine couples the pairs of a launch that have the same size and fills each
+    couple with two pairs per lane, 16-bit halves relative to frames that move with the values.  Cases that move the
+    frames hard or not at all -- identical sequences (the score grows by 2 per column), one residue repeated against
+    itself and against another, unrelated sequences, a shifted copy --, sizes around the limits of the packed path (256
+    columns; rows that are no multiple of 64), launches with a pair left over and with couples of different sizes: every
+    column against the oracle, and the same launches again through the int32 kernel (PSA_FILL_PK=0)."""
+    al = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    rng = np.random.default_rng(9)
+    same = al[rng.integers(0, 20, 12000)]
+    other = al[rng.integers(0, 20, 12000)]
+    poly, polyc = np.full(12000, ord("A"), np.uint8), np.full(12000, ord("C"), np.uint8)
+    shifted = np.concatenate([other[:2000], same[:10000]])
+
+    def rnd(n, m, related):
+        a = al[rng.integers(0, 20, n)]
+        if not related:
+            return a, al[rng.integers(0, 20, m)]
+        b = a[:m].copy() if m <= n else np.concatenate([a, al[rng.integers(0, 20, m - n)]])
+        mut = rng.random(m) < 0.2
+        b[mut] = al[rng.integers(0, 20, int(mut.sum()))]
+        return a, b
+
+    launches = [
+        [(same, same.copy()), (same, other), (poly, poly.copy()), (poly, polyc)],
+        [(same, shifted), (poly, same)],
+        [rnd(300, 256, False), rnd(300, 256, True)],
+        [rnd(1000, 700, False), rnd(1000, 700, True), rnd(640, 700, False)],
+        [rnd(5000, 3000, False), rnd(5000, 3000, True), rnd(333, 3000, False), rnd(333, 3000, True), rnd(5000, 3000, True)],
+        [rnd(255, 255, False), rnd(255, 255, True)],          # below the packed path's 256 columns: the int32 kernel
+    ]
+    want = [[O.align(a, b, 4) for a, b in pairs] for pairs in launches]
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PSA_FILL_PK", mode)
+        for pairs, ref in zip(launches, want):
+            eng = psa_amd.Many(len(pairs), max(a.size for a, _ in pairs), max(b.size for _, b in pairs), traceback=True)
+            for sl, (a, b) in enumerate(pairs):
+                eng.set_pair(sl, a, b)
+            eng.launch()
+            eng.wait()
+            for sl, (a, b) in enumerate(pairs):
+                r = eng.result(sl, a.size, b.size)
+                sc, ai, bj = ref[sl]
+                assert r.score == sc and np.array_equal(r.ai, ai) and np.array_equal(r.bj, bj), (mode, a.size, b.size, sl)
+            eng.close()
+
+
 def test_column_stripes_at_metric_sizes(golden_dir):
     """p > 1 at the sizes the metric is quoted on (simple.cpp:90-99, 136-154, 215-235: the stripes of one pair, here
     jobs of ONE launch with flags between them): the titin pair with p = 8 against the committed md5 of its stdout,
