@@ -562,8 +562,12 @@ def single_gpu(args):
             assert all(gold[sl][0] == got[sl] for sl in range(S) if sl in gold), got
         som.close()
         ms = sum(fm[1:]) / len(fm[1:])
+        so_pk = packed and S % 2 == 0   # (couples through the packed kernel: 10 instructions per step of two cells)
         extra["score_only_2p%d_x%d" % (k, S)] = {"gcups": S * cells1 / (ms * 1e-3) / 1e9, "kernel_ms": ms, "pairs": S,
-                                                 "valu_frac": S * cells1 * OPS_PER_CELL_SCORE / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                                 "kernel": "fill_strips_pk<false>" if so_pk else "fill_strips_v2_dense<false>",
+                                                 "valu_frac": (S * cells1 * 10 / (ms * 1e-3) / 1e12 / PK_PEAK_TOPS) if so_pk else
+                                                              (S * cells1 * OPS_PER_CELL_SCORE / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS),
+                                                 "valu_frac_of_int32_peak_at_8_ops": S * cells1 * OPS_PER_CELL_SCORE / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
                                                  "structural_ceiling": min(1.0, S * cells1 / ((n + m) * 65536.0))}
         # BASELINE config 4's second size: ONE 2^20 x 2^20 pair, score only, one launch
         if os.environ.get("PSA_BENCH_2P20", "1") != "0":

@@ -103,7 +103,7 @@ __device__ __forceinline__ bool pk_expired(Spin& s, PkCtx& c) {
 enum : int { kPkFast = 0, kPkHead = 1, kPkTail = 2 };
 
 // One block of 16 steps.  D0/D1/H/V: the strip's state (named registers: see psa_batch.hip.h on why not a struct).
-template <int MODE>
+template <bool CODES, int MODE>
 __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1, int& H, int& V, const int t0, const int jb) {
     const int lane = c.lane;
     // ---- lane 0's inputs for columns t0..t0+15: ring slots t0+64..t0+79 ----
@@ -146,13 +146,13 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
         const int D = pk_max(M, x3);                                                                                 \
         const int Hn = pk_max(D, pk_add(x2, two));                                                                   \
         const int Vn = pk_max(D, pk_add(x3, two));                                                                   \
-        cd[(k) & 3] = pk_mad(D, eleven, pk_mad(Hn, four, Vn));                                                       \
+        if (CODES) cd[(k) & 3] = pk_mad(D, eleven, pk_mad(Hn, four, Vn));                                            \
         if (MODE == kPkTail) {                                                                                       \
             if (lane == t - (c.W - 1)) { c.cap1 = x1; c.cap2 = x2; c.cap3 = x3; }                                    \
         }                                                                                                            \
         if (MODE != kPkHead || lane <= t) { DREG = D; H = Hn; V = Vn; }                                              \
         if (((k) & 1) == 0) *(int4*)(pa + 2 * (k)) = make_int4(Dm2, Vm1, D1, V);                                     \
-        if (((k) & 3) == 3) {                                                                                        \
+        if (CODES && ((k) & 3) == 3) {                                                                               \
             const unsigned p01 = __builtin_amdgcn_perm((unsigned)cd[1], (unsigned)cd[0], 0x06020400u);               \
             const unsigned p23 = __builtin_amdgcn_perm((unsigned)cd[3], (unsigned)cd[2], 0x06020400u);               \
             c.qdX[4 * jb + ((k) >> 2)] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                               \
@@ -200,7 +200,7 @@ __device__ __forceinline__ void pk_flush(PkCtx& c, PkLds& lds, const int cb, con
     }
 }
 
-template <int MODE>
+template <bool CODES, int MODE>
 __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillArgs& px, const FillArgs& py, int& D0, int& D1, int& H,
                                               int& V, const int sb, const int64_t sg) {
     const int t0 = sb * 64;
@@ -282,11 +282,11 @@ __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillAr
         if (sb == 0 && lane == 0)   // its input has arrived: move the front (see fill_strips_v2's prologue)
             __hip_atomic_fetch_max(px.ticket + kFrontWord, (unsigned)(sg / kNW) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    pk_block<MODE>(c, lds, D0, D1, H, V, t0, 0);
-    pk_block<MODE>(c, lds, D0, D1, H, V, t0 + 16, 1);
-    pk_block<MODE>(c, lds, D0, D1, H, V, t0 + 32, 2);
-    pk_block<MODE>(c, lds, D0, D1, H, V, t0 + 48, 3);
-    {
+    pk_block<CODES, MODE>(c, lds, D0, D1, H, V, t0, 0);
+    pk_block<CODES, MODE>(c, lds, D0, D1, H, V, t0 + 16, 1);
+    pk_block<CODES, MODE>(c, lds, D0, D1, H, V, t0 + 32, 2);
+    pk_block<CODES, MODE>(c, lds, D0, D1, H, V, t0 + 48, 3);
+    if (CODES) {
         uint4* dx = (uint4*)(c.codesX + (size_t)sb * kTileBytes);
         uint4* dy = (uint4*)(c.codesY + (size_t)sb * kTileBytes);
         dx[0] = make_uint4(c.qdX[0], c.qdX[1], c.qdX[2], c.qdX[3]);
@@ -318,6 +318,7 @@ __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillAr
 
 // Jobs 2c and 2c + 1 of the batch are the two pairs of couple c (same n, same W, whole matrix, winner codes on);
 // order[ticket] = couple << 24 | group of four strips.
+template <bool CODES>
 __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     __shared__ PkLds lds;
     __shared__ unsigned wg_ticket;
@@ -379,8 +380,8 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     c.widx = (-lane - ((64 - lane) & 3)) / 4;
 #pragma unroll
     for (int j = 0; j < 17; ++j) { c.mwX[j] = c.trowX[c.widx + j]; c.mwY[j] = c.trowY[c.widx + j]; }
-    c.codesX = px.codes + code_tile_offset(sg, px.Q, 0) + 16 * lane;
-    c.codesY = py.codes + code_tile_offset(sg, px.Q, 0) + 16 * lane;
+    c.codesX = CODES ? px.codes + code_tile_offset(sg, px.Q, 0) + 16 * lane : nullptr;
+    c.codesY = CODES ? py.codes + code_tile_offset(sg, px.Q, 0) + 16 * lane : nullptr;
     c.prod_seen = 0;
     c.cons_seen = 0;
 
@@ -429,11 +430,11 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     // column W-1, capturing
     const int Q = c.Q;
     const int capture_lo = last ? (W - 1) / 64 : Q;
-    pk_superblock<kPkHead>(c, lds, px, py, D0, D1, H, V, 0, sg);
+    pk_superblock<CODES, kPkHead>(c, lds, px, py, D0, D1, H, V, 0, sg);
     for (int sb = 1; sb < capture_lo; ++sb)
-        pk_superblock<kPkFast>(c, lds, px, py, D0, D1, H, V, sb, sg);
+        pk_superblock<CODES, kPkFast>(c, lds, px, py, D0, D1, H, V, sb, sg);
     for (int sb = capture_lo < 1 ? 1 : capture_lo; sb < Q; ++sb)
-        pk_superblock<kPkTail>(c, lds, px, py, D0, D1, H, V, sb, sg);
+        pk_superblock<CODES, kPkTail>(c, lds, px, py, D0, D1, H, V, sb, sg);
 
     if (c.to_hbm) {
         if (Q >= 2) pk_flush(c, lds, Q - 2, D0, false);
@@ -451,8 +452,9 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
 #ifndef PSA_PK_WAVES
 #define PSA_PK_WAVES 2
 #endif
+template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_PK_WAVES, PSA_PK_WAVES))) void fill_strips_pk(FillBatch B) {
-    fill_pk_body(B);
+    fill_pk_body<CODES>(B);
 }
 
 }  // namespace psa

@@ -1488,7 +1488,7 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
     {
         const char* pkv = getenv("PSA_FILL_PK");   // (read at every launch: the tests switch it)
         const bool pk_ok = !(pkv && pkv[0] == '0');
-        if (pk_ok && with_codes && nj >= 2) {
+        if (pk_ok && nj >= 2) {
             int idx[psa::kMaxJobs];
             for (int j = 0; j < nj; ++j) idx[j] = j;
             std::stable_sort(idx, idx + nj, [&](int x, int y) {
@@ -1536,7 +1536,7 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         fb.njobs = npk; fb.order = e->order; fb.ticket = e->ticket;
         HIP_TRY(hipMemsetAsync(e->ticket, 0, 256, st));
         HIP_TRY(hipEventRecord(e->ev[0], st));
-        HIP_TRY(psa::launch_fill_pk(fb, ctotal, st));
+        HIP_TRY(psa::launch_fill_pk(fb, ctotal, with_codes, st));
         for (int x = 0; x < nrest; ++x) {
             const psa::FillArgs2& fj = jobs[rest_of[x]];
             if (int rc = launch_fill_v2(&fj, 1, nullptr, groups[rest_of[x]], fj.base.ticket, with_codes, psa::kKeepoutAloneBytes, st, false)) return rc;

@@ -17,8 +17,8 @@ enum : int { kFillSparse = 0, kFillEdges = 1, kFillDense = 2 };
 
 hipError_t launch_fill_v2_codes(const FillBatch& fb, unsigned total_groups, int kernel, size_t keepout_bytes, hipStream_t st);
 hipError_t launch_fill_v2_score(const FillBatch& fb, unsigned total_groups, int kernel, size_t keepout_bytes, hipStream_t st);
-// couples of pairs, two pairs per lane in packed 16-bit halves (psa_fill_pk.hip.h): jobs 2c, 2c + 1 = couple c; winner codes on
-hipError_t launch_fill_pk(const FillBatch& fb, unsigned total_groups, hipStream_t st);
+// couples of pairs, two pairs per lane in packed 16-bit halves (psa_fill_pk.hip.h): jobs 2c, 2c + 1 = couple c
+hipError_t launch_fill_pk(const FillBatch& fb, unsigned total_groups, bool with_codes, hipStream_t st);
 hipError_t launch_fill_v1_codes(const FillArgs& fa, unsigned strips, hipStream_t st);
 hipError_t launch_fill_v1_score(const FillArgs& fa, unsigned strips, hipStream_t st);
 

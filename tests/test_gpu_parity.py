@@ -303,6 +303,15 @@ def test_packed_fill_couples_match_oracle(monkeypatch):
                 sc, ai, bj = ref[sl]
                 assert r.score == sc and np.array_equal(r.ai, ai) and np.array_equal(r.bj, bj), (mode, a.size, b.size, sl)
             eng.close()
+            # score only (the same kernel without the code bytes)
+            eng = psa_amd.Many(len(pairs), max(a.size for a, _ in pairs), max(b.size for _, b in pairs), traceback=False)
+            for sl, (a, b) in enumerate(pairs):
+                eng.set_pair(sl, a, b)
+            eng.launch()
+            eng.wait()
+            for sl, (a, b) in enumerate(pairs):
+                assert eng.result(sl, a.size, b.size, want_alignment=False).score == ref[sl][0], (mode, "score only", sl)
+            eng.close()
 
 
 def test_column_stripes_at_metric_sizes(golden_dir):
