@@ -103,8 +103,9 @@ double psa_multi_last_fill_ms(void);
  * the pairs go in as few batches of equal size as possible, a batch being up to PSA_MANY_MAX_SLOTS pairs: ONE fill
  * launch over all its pairs (the strips of the pairs interleaved, each pair advancing at the pace of its
  * own chain) and ONE launch of their traceback walks.  Up to three psa_many engines take turns (one when a
- * single batch holds every pair; two where memory is short): a fill is queued while the one before it runs and
- * takes over the chip as that one drains.  One host thread.
+ * single batch holds every pair; two where memory is short): their fills are queued together and share the chip.
+ * Pairs of the same size (taken side by side, whatever their order in the call) are filled two per lane in packed
+ * 16-bit halves (psa_fill_pk.hip.h; PSA_FILL_PK=0: every pair through the int32 kernel).  One host thread.
  */
 int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, const uint8_t* const* b,
                    const int64_t* m, int32_t* scores_out, int32_t** ai_out, int32_t** bj_out,

@@ -1750,13 +1750,19 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
         return PSA_OK;
     };
     for (int x = 0; x < E && rc == PSA_OK; ++x) rc = psa_many_create(&eng[x], slots, n_cap, m_cap, want_al ? PSA_F_TRACEBACK : 0);
+    // pairs of the same size side by side: a launch fills them two per lane (fill_strips_pk)
+    std::vector<int64_t> by_size((size_t)npairs);
+    for (int64_t k = 0; k < npairs; ++k) by_size[(size_t)k] = k;
+    std::stable_sort(by_size.begin(), by_size.end(), [&](int64_t x, int64_t y) { return n[x] != n[y] ? n[x] < n[y] : m[x] < m[y]; });
     int turn = 0;
     for (int64_t k0 = 0; k0 < npairs && rc == PSA_OK; k0 += slots, turn = (turn + 1) % E) {
         if (!held[turn].empty()) rc = collect(turn);
         for (int sl = 0; sl < slots && rc == PSA_OK; ++sl) {
-            const int64_t k = k0 + sl;
-            if (k < npairs) { rc = psa_many_set_pair(eng[turn], sl, a[k], n[k], b[k], m[k]); held[turn].push_back(k); }
-            else rc = psa_many_clear_slot(eng[turn], sl);
+            if (k0 + sl < npairs) {
+                const int64_t k = by_size[(size_t)(k0 + sl)];
+                rc = psa_many_set_pair(eng[turn], sl, a[k], n[k], b[k], m[k]);
+                held[turn].push_back(k);
+            } else rc = psa_many_clear_slot(eng[turn], sl);
         }
         if (rc == PSA_OK) rc = (E == 2) ? psa_many_launch_after(eng[turn], eng[turn ^ 1]) : psa_many_launch(eng[turn]);
     }
