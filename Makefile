@@ -23,7 +23,7 @@ $(OBJDIR)/psa_fill_pk.o: $(CS)/psa_fill_pk.hip $(CS)/psa_fill_pk.hip.h $(FILLH) 
 $(OBJDIR)/psa_trace.o: $(CS)/psa_trace.hip $(CS)/psa_trace1.hip.h $(CS)/psa_trace2.hip.h $(COMMON)
 $(OBJDIR)/psa_batch.o: $(CS)/psa_batch.hip $(CS)/psa_batch.hip.h $(COMMON)
 
-PKWAVES ?= 2
+PKWAVES ?= 3
 $(OBJDIR)/psa_fill_pk.o: HIPFLAGS += -DPSA_PK_WAVES=$(PKWAVES)
 
 $(OBJDIR)/%.o:

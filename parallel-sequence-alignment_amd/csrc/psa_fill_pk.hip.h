@@ -449,8 +449,12 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     }
 }
 
+// Wavefronts per SIMD (Makefile: PKWAVES).  Three: the steady loop fits 168 registers without spills and the launches of
+// three engines sharing the chip run 6 % faster than with two (27.0 against 28.6 ms per launch of 20 pairs), although a
+// launch alone is slower (32.3 against 31.1 ms: more wave slots to fill and to drain).  Four (128 registers) spill in
+// the steady loop: 54 ms.
 #ifndef PSA_PK_WAVES
-#define PSA_PK_WAVES 2
+#define PSA_PK_WAVES 3
 #endif
 template <bool CODES>
 __global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_PK_WAVES, PSA_PK_WAVES))) void fill_strips_pk(FillBatch B) {
