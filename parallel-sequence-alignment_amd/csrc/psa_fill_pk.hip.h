@@ -90,9 +90,7 @@ __device__ __forceinline__ bool pk_expired(Spin& s, PkCtx& c) {
     if ((++s.n & 1023u) == 0) {
         const unsigned long long now = wall_clock64();
         if (s.t0 == 0) s.t0 = now;
-        if (now - s.t0 > kSpinTicks) {
-            __hip_atomic_store(c.abortX, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(c.abortY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (now - s.t0 > kSpinTicks) {   // (the abort words are raised at the strip's end: no store on a path that rejoins the steady loop)
             c.dead = true;
             return true;
         }
@@ -439,6 +437,10 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     if (c.to_hbm) {
         if (Q >= 2) pk_flush(c, lds, Q - 2, D0, false);
         pk_flush(c, lds, Q - 1, D0, false);
+    }
+    if (c.dead) {
+        __hip_atomic_store(c.abortX, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(c.abortY, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (last && i == n) {
         const int bias = (int)(3 * (i + W));
