@@ -307,7 +307,17 @@ def single_gpu(args):
     pairs = slot_pairs(psa_amd, torch, k, S)
     a, b, a_dev, b_dev = pairs[0]
     gold = slot_goldens(k)
-    engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(E)]
+    # (an engine that does not fit after all -- another process on the GPU, a fragmented heap -- costs that engine, not the run)
+    engines = []
+    for _ in range(E):
+        try:
+            engines.append(psa_amd.Many(S, n, m, traceback=True))
+        except Exception as exc:
+            if not engines:
+                raise
+            print("bench: engine %d of %d not created (%s): going on with %d" % (len(engines) + 1, E, exc, len(engines)), file=sys.stderr)
+            break
+    E = len(engines)
     serial = args.serial_fills and E > 1
 
     # The timed region is `steps` batches = launches of S alignments each (--steps 20: 400 alignments; the default 12:
