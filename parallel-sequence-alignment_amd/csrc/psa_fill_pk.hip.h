@@ -65,7 +65,7 @@ struct PkCtx {
     int* prod_post;
     int* cons_post;
     const u64* ginX; const u64* ginY;
-    u64* goutX; u64* goutY; u64* gdumpX; u64* gdumpY;
+    u64* goutX; u64* goutY;
     u64 tag_in, tag_out;
     u64 gbX, gbY;                         // granules of the next superblock's 64 columns, one column per lane
     int carryX, carryY;                   // absolute D of the row above at the column before the next batch (lane-uniform use)
