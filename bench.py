@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=0, help="rows per inter-GPU hand-off (N > 1, stripes); 0 = from the stripe width")
     ap.add_argument("--slots", type=int, default=MAX_SLOTS, help="pairs per launch (1..%d); up to three engines take turns" % MAX_SLOTS)
     ap.add_argument("--engines", type=int, default=3, help="psa_many engines taking turns (2 or 3)")
+    ap.add_argument("--one-process-leg", type=int, default=0, help=argparse.SUPPRESS)   # (internal: the child of the N > 1 run)
+    ap.add_argument("--leg-gold-score", type=int, default=-1, help=argparse.SUPPRESS)
     ap.add_argument("--serial-fills", action="store_true",
                     help="each fill launch alone on the chip (the next engine's fill waits for this one's end); default: "
                          "the next launch is queued at once and fills the chip as this one drains")
@@ -538,8 +540,26 @@ def single_gpu(args):
         if "error" in stripes_info:
             out["stripes_failed"] = True
     if multi_leg:
+        # In a child process, under a deadline: the call has never driven more than one GPU (no multi-GPU box was
+        # available), and whatever goes wrong there must cost that leg only -- the line measured above is still printed.
         try:
-            out["stripes_one_process"] = stripes_one_process(psa_amd, world, k, gold.get(0, (None,))[0])
+            import subprocess
+            env = dict(os.environ)
+            for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "ROLE_RANK"):
+                env.pop(var, None)
+            gs = gold.get(0, (None,))[0]
+            cmd = [sys.executable, os.path.abspath(__file__), "--one-process-leg", str(world), "--log2n", str(k),
+                   "--leg-gold-score", str(-1 if gs is None else gs)]
+            limit = float(os.environ.get("PSA_BENCH_ONE_PROCESS_DEADLINE_S", "150"))
+            try:
+                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit)
+                lines = [ln for ln in cp.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+                out["stripes_one_process"] = json.loads(lines[-1]) if lines else {
+                    "error": "child left with status %d and no result: %s" % (cp.returncode, cp.stderr.decode(errors="replace")[-300:])}
+            except subprocess.TimeoutExpired:
+                out["stripes_one_process"] = {"error": "not finished after %.0f s: abandoned" % limit}
+            except Exception as e:
+                out["stripes_one_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             store.set("psa_one_process_leg_done", "1")
     extra = {}
@@ -771,6 +791,11 @@ def stripes_figures(args, dist, backend, local):
 
 def main():
     args = parse()
+    if args.one_process_leg > 0:   # (child of an N > 1 run: psa_align_multi / psa_score_multi over N GPUs, its own JSON line)
+        import psa_amd
+        print(json.dumps(stripes_one_process(psa_amd, args.one_process_leg, args.log2n,
+                                             None if args.leg_gold_score < 0 else args.leg_gold_score)))
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if (args.gpus > 1 or world > 1) and args.mode == "stripes":
         from bench_multi import multi_gpu   # one pair cut into column stripes (strong scaling) only
