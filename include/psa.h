@@ -120,9 +120,12 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
  *                            caller's buffers are its own again on return).  Device residues are NOT read before the
  *                            next launch, whose binding kernels copy and encode the pairs of all slots together:
  *                            they must stay valid and unchanged until that launch's results have been waited for
- *   launch                   queue ONE fill launch over all bound slots, ONE launch of their walks and
- *                            the copies of the results to pinned host memory; returns at once
- *   wait                     block until those results are on the host
+ *   launch                   queue the binding kernels and ONE fill launch over all bound slots; returns at once
+ *   wait                     block until those results are on the host.  The walks and the copies of the results are
+ *                            queued here, once the fill has ended, on the engine's high-priority stream (queued at the
+ *                            launch they would sit in that stream behind a wait for the fill, and a high-priority
+ *                            queue with an unsatisfied wait was seen to keep fills of normal priority from being
+ *                            dispatched for seconds): call wait when the results are wanted, not long after
  *   result                   score (and T1,T2,T3 at (n, m) when triple_out is not NULL) of a slot; with
  *                            ai/bj (capacity cap >= 2 (n + m) + 2 each) also the finished alignment,
  *                            prefix fix-up of simple.cpp:279-290 applied

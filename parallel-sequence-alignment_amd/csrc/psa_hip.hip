@@ -11,6 +11,7 @@
 #include <cstring>
 #include <random>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "psa_host.h"
@@ -1295,24 +1296,70 @@ struct psa_many {
     int32_t* d_res = nullptr;       // slots x kResultWords: walk state, final triple, abort word of every slot (collect_results)
     int32_t* h_res = nullptr;       // pinned copy
     std::vector<int32_t*> h_ai, h_bj;   // pinned: reversed columns as the walk emitted them
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // fill start / end, walks end, results on the host
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // fill start / end, walks end, results on the host, walks start
     bool launched = false;
+    bool walks_queued = false;      // the launch's walks and result copies are on the walk stream (see queue_walks)
 };
 
 namespace {
+
+// Stream pairs of the engines (fill stream, normal priority; walk stream, highest).  HIP multiplexes the streams of a
+// priority onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default); with five engines -- five streams per priority
+// -- a launch was seen never to complete (a walk stream's wait for its fill ahead of that fill in a shared queue).  So a
+// device has at most kEnginePairs pairs: further engines share the pairs of the first ones, their work takes turns in
+// stream order, and nothing can wait for something queued behind it.
+constexpr int kEnginePairs = 3;
+struct EnginePair { int device = -1; hipStream_t fill = nullptr, walk = nullptr; int users = 0; };
+std::mutex g_pair_mutex;
+std::vector<EnginePair> g_pairs;
+
+hipError_t acquire_engine_pair(int device, hipStream_t* fill, hipStream_t* walk) {
+    std::lock_guard<std::mutex> lock(g_pair_mutex);
+    EnginePair* best = nullptr;
+    int on_device = 0;
+    for (auto& p : g_pairs)
+        if (p.device == device) { ++on_device; if (!best || p.users < best->users) best = &p; }
+    if (!best || (best->users > 0 && on_device < kEnginePairs)) {
+        int least = 0, greatest = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e != hipSuccess) return e;
+        EnginePair np;
+        np.device = device;
+        if ((e = hipStreamCreateWithPriority(&np.fill, hipStreamNonBlocking, (least + greatest) / 2)) != hipSuccess) return e;
+        const char* wp = getenv("PSA_WALK_PRIORITY");   // (experiment switch: "normal" puts the walk streams in the fills' class)
+        const int walk_prio = (wp && !strcmp(wp, "normal")) ? (least + greatest) / 2 : greatest;
+        if ((e = hipStreamCreateWithPriority(&np.walk, hipStreamNonBlocking, walk_prio)) != hipSuccess) { hipStreamDestroy(np.fill); return e; }
+        g_pairs.push_back(np);
+        best = &g_pairs.back();
+    }
+    ++best->users;
+    *fill = best->fill; *walk = best->walk;
+    return hipSuccess;
+}
+void release_engine_pair(hipStream_t fill) {
+    std::lock_guard<std::mutex> lock(g_pair_mutex);
+    for (size_t k = 0; k < g_pairs.size(); ++k)
+        if (g_pairs[k].fill == fill) {
+            if (--g_pairs[k].users == 0) {
+                hipStreamDestroy(g_pairs[k].fill); hipStreamDestroy(g_pairs[k].walk);
+                g_pairs.erase(g_pairs.begin() + (long)k);
+            }
+            return;
+        }
+}
 
 void free_many(psa_many* e) {
     if (!e) return;
     DeviceGuard g(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
-    if (e->walk_stream) { hipStreamSynchronize(e->walk_stream); hipStreamDestroy(e->walk_stream); }
+    if (e->walk_stream) hipStreamSynchronize(e->walk_stream);
     for (auto* s : e->st) free_stripe(s);
     for (auto* p : e->h_ai) hipHostFree(p);
     for (auto* p : e->h_bj) hipHostFree(p);
     hipFree(e->ticket); hipFree(e->order); hipFree(e->d_res);
     hipHostFree(e->h_res);
     for (auto& x : e->ev) if (x) hipEventDestroy(x);
-    if (e->stream) hipStreamDestroy(e->stream);
+    if (e->stream) release_engine_pair(e->stream);
     delete e;
 }
 
@@ -1362,11 +1409,7 @@ int psa_many_create(psa_many** out, int slots, int64_t n_cap, int64_t m_cap, uin
         // engines take turns).  Every fill stream has the SAME (normal) priority: with one engine's fill on the lowest
         // priority the high-priority stream's wait for that fill never ended (two engines in flight: the queue
         // scheduler starves the lowest class while a higher one has work, even work that waits for it).
-        int least = 0, greatest = 0;
-        MANY_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const int prio = (least + greatest) / 2;
-        MANY_TRY(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio));
-        MANY_TRY(hipStreamCreateWithPriority(&e->walk_stream, hipStreamNonBlocking, greatest));
+        MANY_TRY(acquire_engine_pair(e->device, &e->stream, &e->walk_stream));
     }
     for (auto& x : e->ev) MANY_TRY(hipEventCreate(&x));
     MANY_TRY(hipMalloc(&e->ticket, 256));
@@ -1570,10 +1613,24 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
                                     nj > 1 ? psa::kKeepoutManyBytes : psa::kKeepoutAloneBytes, st, nj > 1 && dense_ok)) return rc;
     } else HIP_TRY(hipEventRecord(e->ev[0], st));
     HIP_TRY(hipEventRecord(e->ev[1], st));
-    // the walks: one workgroup per pair, all in one launch, each starting from its pair's final pick; they and the
-    // copies of the results go to the engine's high-priority stream, behind the fill
-    st = e->walk_stream;
-    HIP_TRY(hipStreamWaitEvent(st, e->ev[1], 0));
+    e->launched = true;
+    e->walks_queued = false;
+    return PSA_OK;
+}
+
+namespace {
+// The walks of a launch -- one workgroup per pair, all in one launch, each starting from its pair's final pick -- and the
+// copies of the results, on the engine's high-priority stream.  Queued by psa_many_wait once the fill HAS ENDED, not at
+// the launch behind a wait for the fill's event: a high-priority queue that holds an unsatisfied wait keeps the queue
+// scheduler from the normal-priority queues -- with short launches on two or more engines the fills it waited for were
+// not dispatched for seconds (launches of 4 096 x 4 096 pairs: waits of 1-58 s; nothing of the kind with the walk streams
+// at normal priority, which costs the 2^16 bench 13 %).  A caller in the usual loop (launch the other engines, wait for
+// this one) loses nothing: it is in psa_many_wait when the fill ends.
+int queue_walks(psa_many* e) {
+    const bool with_codes = (e->flags & PSA_F_TRACEBACK) != 0;
+    HIP_TRY(hipEventSynchronize(e->ev[1]));
+    hipStream_t st = e->walk_stream;
+    HIP_TRY(hipEventRecord(e->ev[4], st));
     if (with_codes) {
         psa::TraceBatch tb;
         memset(&tb, 0, sizeof tb);
@@ -1614,15 +1671,18 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         HIP_TRY(hipMemcpyAsync(e->h_bj[k], s->tb_bj, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipEventRecord(e->ev[3], st));
-    e->launched = true;
+    e->walks_queued = true;
     return PSA_OK;
 }
+}  // namespace
+
 
 int psa_many_wait(psa_many* e) {
     if (!e) return fail(PSA_E_ARG, "psa_many_wait: null engine");
     if (!e->launched) return PSA_OK;
     DeviceGuard g(e->device);
     if (g.rc) return g.rc;
+    if (!e->walks_queued) if (int rc = queue_walks(e)) return rc;
     HIP_TRY(hipEventSynchronize(e->ev[3]));
     e->launched = false;
     return PSA_OK;
@@ -1668,7 +1728,7 @@ int psa_many_last_ms(psa_many* e, float* fill_ms_out, float* walk_ms_out) {
     DeviceGuard g(e->device);
     if (g.rc) return g.rc;
     if (fill_ms_out) HIP_TRY(hipEventElapsedTime(fill_ms_out, e->ev[0], e->ev[1]));
-    if (walk_ms_out) HIP_TRY(hipEventElapsedTime(walk_ms_out, e->ev[1], e->ev[2]));
+    if (walk_ms_out) HIP_TRY(hipEventElapsedTime(walk_ms_out, e->ev[4], e->ev[2]));
     return PSA_OK;
 }
 

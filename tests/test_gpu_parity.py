@@ -314,6 +314,35 @@ def test_packed_fill_couples_match_oracle(monkeypatch):
             eng.close()
 
 
+def test_many_short_launches_on_several_engines_do_not_stall():
+    """Five engines, short launches (2 048 x 2 048 pairs) one behind the other: with the walks queued at the launch behind a
+    wait for the fill's event on a HIGH-priority stream, the queue scheduler left the fills undispatched for seconds
+    (waits of 1-58 s per launch, no error); the walks are now queued by psa_many_wait once the fill has ended.  Bounded
+    time for 30 launches, results against the oracle."""
+    import time
+    n = m = 2048
+    S, E = 6, 5
+    pairs = [(psa_amd.synth_protein(77 + s, n), psa_amd.synth_protein(7700 + s, m)) for s in range(S)]
+    want = [O.align(a, b, 2) for a, b in pairs]
+    engines = [psa_amd.Many(S, n, m, traceback=True) for _ in range(E)]
+    t0 = time.time()
+    for it in range(6):
+        for e in engines:
+            if it > 0:
+                e.wait()
+                for sl in range(S):
+                    r = e.result(sl, n, m)
+                    sc, ai, bj = want[sl]
+                    assert r.score == sc and np.array_equal(r.ai, ai) and np.array_equal(r.bj, bj), (it, sl)
+            for sl, (a, b) in enumerate(pairs):
+                e.set_pair(sl, a, b)
+            e.launch()
+    for e in engines:
+        e.wait()
+        e.close()
+    assert time.time() - t0 < 20.0, "launches stalled: %.1f s for 30 launches of six 2 048 x 2 048 pairs" % (time.time() - t0)
+
+
 def test_column_stripes_at_metric_sizes(golden_dir):
     """p > 1 at the sizes the metric is quoted on (simple.cpp:90-99, 136-154, 215-235: the stripes of one pair, here
     jobs of ONE launch with flags between them): the titin pair with p = 8 against the committed md5 of its stdout,
