@@ -257,6 +257,9 @@ def throughput_job(engines, pairs, n, m, batches, serial_fills, ref_event=None, 
         for sl in range(held[x]):
             r = eng.result(sl, n, m)
             res.append((sl, r.score, len(r.ai)))
+            for other in engines:   # (a fill that has ended meanwhile: its walks are queued now, not at its turn)
+                if other is not eng:
+                    other.poll()
         f, w = eng.last_ms()
         fills.append((f, held[x])); walks.append(w)
         if ref_event is not None:

@@ -149,6 +149,10 @@ int psa_many_launch(psa_many* e);
  * byte alphabet). */
 int psa_many_launch_after(psa_many* e, psa_many* after);
 int psa_many_wait(psa_many* e);
+/* Without blocking: 1 when the last launch's results are on the host (or nothing is launched), 0 when not yet, < 0 on
+ * error.  Queues the engine's walks and result copies as soon as its fill has ended: a caller that is busy with the
+ * results of one engine calls this on the others now and then, so that their walks do not wait for their turn. */
+int psa_many_poll(psa_many* e);
 int psa_many_result(psa_many* e, int slot, int32_t* score_out, int32_t triple_out[3], int32_t* ai,
                     int32_t* bj, int64_t cap, int64_t* len_out);
 int psa_many_last_ms(psa_many* e, float* fill_ms_out, float* walk_ms_out);

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "psa_many_set_pair": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "psa_many_set_pair_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, _i64, C.c_void_p, _i64]),
     "psa_many_clear_slot": (C.c_int, [C.c_void_p, C.c_int]),
+    "psa_many_poll": (C.c_int, [C.c_void_p]),
     "psa_many_fill_ms_since": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "psa_many_launch": (C.c_int, [C.c_void_p]),
     "psa_many_launch_after": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -411,6 +412,13 @@ class Many:
         f, w = C.c_float(), C.c_float()
         _check(lib().psa_many_last_ms(self._h, C.byref(f), C.byref(w)))
         return f.value, w.value
+
+    def poll(self):
+        """True when the last launch's results are on the host; queues the walks of a fill that has ended (no blocking)."""
+        rc = lib().psa_many_poll(self._h)
+        if rc < 0:
+            _check(rc)
+        return rc == 1
 
     def fill_ms_since(self, ref_event):
         """(begin, end) of the last launch's fill in ms after `ref_event` (a hipEvent_t handle, e.g. torch.cuda.Event.cuda_event)."""

@@ -1677,6 +1677,23 @@ int queue_walks(psa_many* e) {
 }  // namespace
 
 
+int psa_many_poll(psa_many* e) {
+    if (!e) return fail(PSA_E_ARG, "psa_many_poll: null engine");
+    if (!e->launched) return 1;
+    DeviceGuard g(e->device);
+    if (g.rc) return g.rc;
+    if (!e->walks_queued) {
+        const hipError_t q = hipEventQuery(e->ev[1]);
+        if (q == hipErrorNotReady) return 0;
+        if (q != hipSuccess) return fail(PSA_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+        if (int rc = queue_walks(e)) return rc;
+    }
+    const hipError_t q = hipEventQuery(e->ev[3]);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) return fail(PSA_E_HIP, "hipEventQuery failed: %s", hipGetErrorString(q));
+    return 1;
+}
+
 int psa_many_wait(psa_many* e) {
     if (!e) return fail(PSA_E_ARG, "psa_many_wait: null engine");
     if (!e->launched) return PSA_OK;
@@ -1805,6 +1822,8 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
                 if (!ai_out[k] || !bj_out[k]) return fail(PSA_E_NOMEM, "psa_align_many: host allocation failed");
                 if (int r = psa_many_result(eng[x], (int)sl, &scores_out[k], nullptr, ai_out[k], bj_out[k], cap, &len_out[k])) return r;
             } else if (int r = psa_many_result(eng[x], (int)sl, &scores_out[k], nullptr, nullptr, nullptr, 0, nullptr)) return r;
+            // (an engine whose fill has ended meanwhile gets its walks queued now, not when its turn to be collected comes)
+            for (int y = 0; y < 3; ++y) if (y != x && eng[y]) { const int pr = psa_many_poll(eng[y]); if (pr < 0) return pr; }
         }
         held[x].clear();
         return PSA_OK;
