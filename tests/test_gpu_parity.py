@@ -314,6 +314,35 @@ def test_packed_fill_couples_match_oracle(monkeypatch):
             eng.close()
 
 
+def test_packed_fill_sizes_around_strip_and_superblock_boundaries():
+    """The packed fill at row counts around multiples of 64 (strips: lanes without a row, a last strip of one row) and
+    column counts around multiples of 64 (superblocks: where the frames move and the capturing tail begins), four pairs per
+    launch (unrelated, periodic copies of A, a mutated one): every column against the oracle."""
+    rng = np.random.default_rng(5)
+    al = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    shapes = [(64, 256), (65, 257), (127, 300), (128, 319), (129, 320), (191, 321), (192, 383), (193, 384), (255, 385),
+              (256, 447), (257, 448), (320, 449), (511, 511), (512, 512), (513, 513), (64, 1025), (1000, 256), (2049, 2047)]
+    for n, m in shapes:
+        pairs = []
+        for j in range(4):
+            a = al[rng.integers(0, 20, n)]
+            b = al[rng.integers(0, 20, m)] if j % 2 == 0 else np.resize(a, m).copy()
+            if j == 3:
+                mut = rng.random(m) < 0.1
+                b[mut] = al[rng.integers(0, 20, int(mut.sum()))]
+            pairs.append((a, b))
+        eng = psa_amd.Many(4, n, m, traceback=True)
+        for sl, (a, b) in enumerate(pairs):
+            eng.set_pair(sl, a, b)
+        eng.launch()
+        eng.wait()
+        for sl, (a, b) in enumerate(pairs):
+            r = eng.result(sl, n, m)
+            sc, ai, bj = O.align(a, b, 2)
+            assert r.score == sc and np.array_equal(r.ai, ai) and np.array_equal(r.bj, bj), (n, m, sl)
+        eng.close()
+
+
 def test_many_short_launches_on_several_engines_do_not_stall():
     """Five engines, short launches (2 048 x 2 048 pairs) one behind the other: with the walks queued at the launch behind a
     wait for the fill's event on a HIGH-priority stream, the queue scheduler left the fills undispatched for seconds
