@@ -69,7 +69,8 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
 int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
               int32_t* score_out, int32_t triple_out[3]);
 
-/* Free the device buffers psa_align / psa_score keep for the calling thread (see psa_align). */
+/* Free the device buffers psa_align / psa_score / psa_*_multi and the engines psa_align_many keep for the calling
+ * thread (see psa_align, psa_align_many). */
 void psa_release_cache(void);
 
 /*
@@ -106,6 +107,10 @@ double psa_multi_last_fill_ms(void);
  * single batch holds every pair; two where memory is short): their fills are queued together and share the chip.
  * Pairs of the same size (taken side by side, whatever their order in the call) are filled two per lane in packed
  * 16-bit halves (psa_fill_pk.hip.h; PSA_FILL_PK=0: every pair through the int32 kernel).  One host thread.
+ * The engines (up to 70 % of the free device memory when alignments are wanted) stay allocated for the calling thread's
+ * next psa_align_many of the same kind (with or without alignments) whose pairs and batches are no larger; they are
+ * freed by psa_release_cache(), by a call they do not fit, by a psa_align / psa_score / psa_align_banded call of this
+ * thread whose buffers would take more than 70 % of the memory left beside them, and by its psa_*_multi calls.
  */
 int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, const uint8_t* const* b,
                    const int64_t* m, int32_t* scores_out, int32_t** ai_out, int32_t** bj_out,

@@ -746,6 +746,10 @@ struct StripeSet {
 thread_local StripeSet* g_cache = nullptr;
 }  // namespace
 void psa_drop_multi_cache_impl();   // (defined with the multi-GPU calls below)
+void psa_drop_many_cache_impl();    // (defined with psa_align_many below)
+// psa_align_many's engines go when an allocation of `need` bytes would take more than 70 % of what is free beside them
+// (freeing and rebuilding them costs seconds, so not for a pair that fits anyway).
+void psa_make_room(double need);
 namespace {
 inline void drop_multi_fwd() { psa_drop_multi_cache_impl(); }
 
@@ -765,6 +769,7 @@ int get_stripes(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p,
     const bool hit = set.device == dev && set.n == n && set.m == m && set.p == p && set.flags == flags && !set.st.empty();
     if (!hit) {
         set.clear();
+        psa_make_room(((flags & PSA_F_TRACEBACK) ? 1.05 * (double)n * (double)m : 0.0) + 64.0 * (double)(n + m) * p + (double)(64 << 20));
         set.device = dev; set.n = n; set.m = m; set.flags = flags;
         const int64_t block = m / p;   // column stripes exactly as simple.cpp:90-99 cuts them; zero-width stripes (p > m) own no cell
         for (int id = 0; id < p; ++id) {
@@ -897,9 +902,16 @@ int run_stripes(StripeSet& set, int32_t triple[3]) {
 
 extern "C" {
 
-void psa_release_cache(void) {
+namespace {
+void release_pair_caches() {   // the objects psa_align / psa_score / the multi-GPU calls keep for their next call
     if (g_cache) { g_cache->clear(); delete g_cache; g_cache = nullptr; }
-    drop_multi_fwd();   // (the multi-GPU calls' objects)
+    drop_multi_fwd();
+}
+}  // namespace
+
+void psa_release_cache(void) {
+    release_pair_caches();
+    psa_drop_many_cache_impl();   // (psa_align_many's engines)
 }
 
 int psa_score(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, int32_t* score_out,
@@ -939,6 +951,7 @@ int psa_align(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, int p, i
         const double code_bytes = (double)n * (double)m;
         const bool forced = getenv("PSA_BAND_ROWS") != nullptr;
         const bool cached = g_cache && g_cache->n == n && g_cache->m == m && g_cache->p == p && g_cache->flags == PSA_F_TRACEBACK;
+        if (!cached) psa_make_room(1.05 * code_bytes + (double)(64 << 20));   // (before the memory is measured)
         if (forced || (!cached && hipMemGetInfo(&free_b, &total_b) == hipSuccess && code_bytes > 0.7 * (double)free_b)) {
             psa_release_cache();
             return psa_align_banded(a, n, b, m, 0, score_out, ai_out, bj_out, len_out);
@@ -982,6 +995,7 @@ int psa_align_banded(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, i
     if (int rc = need_device()) return rc;
     *ai_out = *bj_out = nullptr;
     *len_out = 0;
+    psa_make_room((double)(24LL << 30));   // (a band takes 8 GiB when three times that are free, band_rows_for)
     psa_stripe* s = nullptr;
     g_band_rows_request = band_rows;
     int rc = psa_stripe_create(&s, a, n, b, m, 0, m, PSA_F_TRACEBACK | PSA_F_BANDED);
@@ -1097,6 +1111,7 @@ int multi_fill(const uint8_t* a, int64_t n, const uint8_t* b, int64_t m, const i
     const bool reuse = g_multi && g_multi->n == n && g_multi->m == m && g_multi->mode == flags && g_multi->dev_key == key;
     if (!reuse) {
         drop_multi();
+        psa_drop_many_cache_impl();
         g_multi = new MultiRun();
     }
     int rc = multi_fill_on(*g_multi, reuse, a, n, b, m, devices, ngpu, flags, t);
@@ -1763,6 +1778,30 @@ int64_t psa_many_code_bytes(const psa_many* e, int slot) {
     return (e && slot >= 0 && slot < e->slots && e->bound[slot] == 1) ? (int64_t)e->st[slot]->code_bytes : 0;
 }
 
+// The engines of the thread's last psa_align_many call, kept for its next one: allocating and freeing a quarter of a
+// terabyte of code buffers per call took 0.4 s the first and 3.8 s the second time for 60 pairs of 2^16 x 2^16 that need
+// 0.08 s of GPU time.  psa_release_cache() frees them.
+struct ManyCache {
+    psa_many* eng[3] = {nullptr, nullptr, nullptr};
+    int E = 0, slots = 0, device = -1;
+    int64_t n_cap = 0, m_cap = 0;
+    uint32_t flags = 0;
+};
+thread_local ManyCache* g_many = nullptr;
+}  // extern "C" (closed for the helper below)
+void psa_make_room(double need) {
+    if (!g_many) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > 0.7 * (double)free_b) psa_drop_many_cache_impl();
+}
+void psa_drop_many_cache_impl() {
+    if (!g_many) return;
+    for (auto*& e : g_many->eng) { free_many(e); e = nullptr; }
+    delete g_many;
+    g_many = nullptr;
+}
+extern "C" {
+
 // run() in a loop (simple.cpp:311 called once per pair): the pairs go through two engines that take
 // turns, so that the walks and copies of one batch run beside the fill of the next.
 int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, const uint8_t* const* b, const int64_t* m,
@@ -1784,11 +1823,22 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
     // runs and takes over the chip as that one drains, and nobody waits for an engine's walks, which get their turn at
     // the next drain --, else two, each fill after the other's end (the walks and copies of one beside the fill of the
     // other); slots before engines (20 + 20 rather than 3 x 13).  70 % of the free memory at most.
-    psa_release_cache();
+    release_pair_caches();
+    const uint32_t eflags = want_al ? PSA_F_TRACEBACK : 0;
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    auto slot_bytes = [](bool codes, int64_t nc, int64_t mc) {
+        return (codes ? (double)nc * (double)mc * 1.05 : 0.0) + 64.0 * (double)(nc + mc) + (1 << 20);
+    };
+    // (engines kept from the last call can serve this one if they are of its kind and large enough; their memory counts
+    // as free for the plan, and they go if the plan wants more than they are)
+    bool compatible = g_many && g_many->device == device && g_many->flags == eflags && g_many->n_cap >= n_cap && g_many->m_cap >= m_cap;
+    if (g_many && !compatible) psa_drop_many_cache_impl();
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    const double per_slot = (want_al ? (double)n_cap * (double)m_cap * 1.05 : 0.0) + 64.0 * (double)(n_cap + m_cap) + (1 << 20);
-    const int64_t fit = (int64_t)std::min<double>(1e6, 0.7 * (double)free_b / per_slot);   // slots the memory holds
+    const double per_slot = compatible ? slot_bytes(want_al, g_many->n_cap, g_many->m_cap) : slot_bytes(want_al, n_cap, m_cap);
+    const double held_b = compatible ? per_slot * g_many->E * g_many->slots : 0.0;
+    const int64_t fit = (int64_t)std::min<double>(1e6, 0.7 * ((double)free_b + held_b) / per_slot);   // slots the memory holds
     int slots = (int)std::min<int64_t>(std::min<int64_t>(psa::kMaxJobs, fit), npairs);
     int E = 1;
     if (slots >= 1) {
@@ -1828,7 +1878,18 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
         held[x].clear();
         return PSA_OK;
     };
-    for (int x = 0; x < E && rc == PSA_OK; ++x) rc = psa_many_create(&eng[x], slots, n_cap, m_cap, want_al ? PSA_F_TRACEBACK : 0);
+    if (compatible && (g_many->E < E || g_many->slots < slots)) { psa_drop_many_cache_impl(); compatible = false; }
+    if (compatible) {
+        for (int x = 0; x < E; ++x) eng[x] = g_many->eng[x];
+    } else {
+        g_many = new ManyCache();
+        g_many->device = device; g_many->flags = eflags; g_many->n_cap = n_cap; g_many->m_cap = m_cap;
+        for (int x = 0; x < E && rc == PSA_OK; ++x) {
+            rc = psa_many_create(&eng[x], slots, n_cap, m_cap, eflags);
+            g_many->eng[x] = eng[x];
+        }
+        g_many->E = E; g_many->slots = slots;
+    }
     // pairs of the same size side by side: a launch fills them two per lane (fill_strips_pk)
     std::vector<int64_t> by_size((size_t)npairs);
     for (int64_t k = 0; k < npairs; ++k) by_size[(size_t)k] = k;
@@ -1836,8 +1897,8 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
     int turn = 0;
     for (int64_t k0 = 0; k0 < npairs && rc == PSA_OK; k0 += slots, turn = (turn + 1) % E) {
         if (!held[turn].empty()) rc = collect(turn);
-        for (int sl = 0; sl < slots && rc == PSA_OK; ++sl) {
-            if (k0 + sl < npairs) {
+        for (int sl = 0; sl < g_many->slots && rc == PSA_OK; ++sl) {   // (kept engines may have more slots than this call uses)
+            if (sl < slots && k0 + sl < npairs) {
                 const int64_t k = by_size[(size_t)(k0 + sl)];
                 rc = psa_many_set_pair(eng[turn], sl, a[k], n[k], b[k], m[k]);
                 held[turn].push_back(k);
@@ -1846,9 +1907,11 @@ int psa_align_many(int64_t npairs, const uint8_t* const* a, const int64_t* n, co
         if (rc == PSA_OK) rc = (E == 2) ? psa_many_launch_after(eng[turn], eng[turn ^ 1]) : psa_many_launch(eng[turn]);
     }
     for (int x = 0; x < E && rc == PSA_OK; ++x) if (!held[(turn + x) % E].empty()) rc = collect((turn + x) % E);
-    for (int x = 0; x < E; ++x) free_many(eng[x]);
-    if (rc != PSA_OK && want_al)
-        for (int64_t k = 0; k < npairs; ++k) { free(ai_out[k]); free(bj_out[k]); ai_out[k] = bj_out[k] = nullptr; }
+    if (rc != PSA_OK) {
+        psa_drop_many_cache_impl();   // (engines in an unknown state: gone)
+        if (want_al)
+            for (int64_t k = 0; k < npairs; ++k) { free(ai_out[k]); free(bj_out[k]); ai_out[k] = bj_out[k] = nullptr; }
+    }
     return rc;
 }
 

@@ -632,6 +632,37 @@ def test_align_many_matches_oracle():
     assert [r.score for r in scores] == [r.score for r in got]
 
 
+def test_align_many_kept_engines_serve_later_calls():
+    """psa_align_many keeps its engines for the thread's next call: a call with fewer and smaller pairs (slots of the
+    last call left over), one of the other kind (scores only), one with larger pairs and more batches (new engines),
+    a single-pair call in between and psa_release_cache() -- every result against the oracle."""
+    rng = np.random.default_rng(47)
+
+    def make(shapes):
+        return [(rng.integers(65, 69, n).astype(np.uint8), rng.integers(65, 69, m).astype(np.uint8)) for n, m in shapes]
+
+    def check(pairs, alignments=True):
+        got = psa_amd.align_many(pairs, alignments=alignments)
+        for (a, b), res in zip(pairs, got):
+            sc, ai, bj = O.align(a, b)
+            assert res.score == sc, (a.size, b.size)
+            if alignments:
+                assert np.array_equal(res.ai, ai) and np.array_equal(res.bj, bj), (a.size, b.size)
+
+    psa_amd.release_cache()
+    check(make([(900, 800)] * 12 + [(512, 640)] * 5))           # one batch of 17
+    check(make([(300, 280)] * 3))                               # 3 of the 17 slots
+    check(make([(640, 512)] * 4), alignments=False)             # engines without codes
+    check(make([(900, 800)] * 2))
+    one = make([(700, 900)])[0]
+    assert psa_amd.align(one[0], one[1]).score == O.align(one[0], one[1])[0]
+    check(make([(1200, 1100)] * 45 + [(64, 64)] * 2))           # three batches, larger pairs
+    check(make([(256, 256)] * 21))                              # two batches on engines of 16 slots
+    psa_amd.release_cache()
+    check(make([(300, 280)] * 3))
+    psa_amd.release_cache()
+
+
 def test_many_engine_reuse_and_device_inputs():
     """The engine itself: slots re-bound to pairs of other sizes between launches, residues taken from device memory."""
     import torch
