@@ -24,7 +24,11 @@ $(OBJDIR)/psa_trace.o: $(CS)/psa_trace.hip $(CS)/psa_trace1.hip.h $(CS)/psa_trac
 $(OBJDIR)/psa_batch.o: $(CS)/psa_batch.hip $(CS)/psa_batch.hip.h $(COMMON)
 
 PKWAVES ?= 3
-$(OBJDIR)/psa_fill_pk.o: HIPFLAGS += -DPSA_PK_WAVES=$(PKWAVES)
+$(OBJDIR)/psa_fill_pk.o: HIPFLAGS += -DPSA_PK_WAVES=$(PKWAVES) $(PKEXTRA)
+# (strips per workgroup of the packed kernel: host and kernel must agree, so for every object)
+ifdef PKNW
+HIPFLAGS += -DPSA_PK_NW=$(PKNW)
+endif
 
 $(OBJDIR)/%.o:
 	mkdir -p $(OBJDIR)

@@ -49,6 +49,14 @@ constexpr int kFrontWord = 32;  // control block: [0] ticket, [1] abort flag, [3
 // Bounded waiting inside kernels: wall-clock time (s_memrealtime, 100 MHz), see Spin in psa_fill_v2.hip.h
 constexpr unsigned long long kSpinTicks = 30ull * 100000000ull;   // 30 s
 constexpr int kNW = 4;         // strips (wavefronts) per workgroup
+// The packed kernel (psa_fill_pk.hip.h) has its own constant (Makefile: PKNW), measured on the bench's launches of 20
+// pairs with three wavefronts per SIMD: 4 strips per workgroup 3 200 GCUPS, 3: 2 966, 2: 2 835, 6: 2 356, 12: 2 940.
+// Four wavefronts land one on each SIMD of a CU; other sizes leave the SIMDs unevenly loaded, and that outweighs the
+// hand-overs through HBM granules that larger workgroups save (a launch alone: 30.0 / 31.3 / 31.8 / 37.6 / 35.0 ms).
+#ifndef PSA_PK_NW
+#define PSA_PK_NW 4
+#endif
+constexpr int kPkNW = PSA_PK_NW;
 constexpr int kMaxSym = 256;   // rows of the substitution table: one per distinct residue of A (only the rows of residues that occur are built)
 constexpr int kTabPad = 16;    // table words (8 columns each) of padding in front of a row
 

@@ -28,13 +28,13 @@ constexpr int kPkStage = 128;   // staging slots of a strip that publishes throu
 constexpr int kPkFrames = 8;    // published frames per ring (a producer is at most three superblocks ahead)
 
 struct __attribute__((aligned(128))) PkLds {
-    int2 ring[kNW][kRing];          // ring[w]: input of wave w; slot s = (D of column s-65, V of column s-64), both pairs packed
-    int2 stage[kNW][kPkStage];      // a wave's last row on its way to HBM granules (same slot numbering)
-    int dummy[kNW][320];            // where lanes other than 63 drop their publish writes (16 bytes a lane)
-    int dummy2[kNW][64];            // where lanes that own no counter drop their counter posts
-    int prod[kNW];                  // steps completed by the producer of ring[w]
-    int cons[kNW];                  // ring[w] slots below this number have been read
-    int frame[kNW][kPkFrames][2];   // frame[w][k & 7]: bases (pair X, pair Y) of ring[w]'s producer during its superblock k
+    int2 ring[kPkNW][kRing];          // ring[w]: input of wave w; slot s = (D of column s-65, V of column s-64), both pairs packed
+    int2 stage[kPkNW][kPkStage];      // a wave's last row on its way to HBM granules (same slot numbering)
+    int dummy[kPkNW][320];            // where lanes other than 63 drop their publish writes (16 bytes a lane)
+    int dummy2[kPkNW][64];            // where lanes that own no counter drop their counter posts
+    int prod[kPkNW];                  // steps completed by the producer of ring[w]
+    int cons[kPkNW];                  // ring[w] slots below this number have been read
+    int frame[kPkNW][kPkFrames][2];   // frame[w][k & 7]: bases (pair X, pair Y) of ring[w]'s producer during its superblock k
 };
 
 typedef short pkv __attribute__((ext_vector_type(2)));
@@ -72,8 +72,8 @@ struct PkCtx {
     const uint32_t* trowX; const uint32_t* trowY;
     int msh, widx;                        // widx: word of the table row that holds this lane's column of step 0
     unsigned mwX[17], mwY[17];            // table words of this superblock's 64 columns (+ alignment spill)
-    unsigned qdX[16], qdY[16];            // winner codes of the superblock
-    uint8_t* codesX; uint8_t* codesY;     // code tiles of this strip, block 0 of superblock 0, this lane's 16 bytes
+    uint8_t* codesX; uint8_t* codesY;     // (wave-uniform) code tiles of this strip: block 0 of superblock 0
+    unsigned code_lane;                   // this lane's 16 bytes inside a block of a tile
     int cap1, cap2, cap3;                 // x1, x2, x3 at column W-1 (relative), per lane, and the frame they were taken in
     int capBX, capBY;
     unsigned* abortX; unsigned* abortY;
@@ -99,16 +99,36 @@ __device__ __forceinline__ bool pk_expired(Spin& s, PkCtx& c) {
 }
 
 enum : int { kPkFast = 0, kPkHead = 1, kPkTail = 2 };
+// Where a strip's row above comes from: the steady loop is compiled once for the strips fed through LDS and once for the
+// first strip of a workgroup (granules from HBM), head and tail decide at run time (kPkInAny).  In one loop for both,
+// the registers that hold the next batch of granules are carried around the loop, and on the path of the strips that
+// never load them the compiler still has to assume a load in flight: it put s_waitcnt vmcnt(0) there, at the start of
+// every superblock of EVERY strip, right behind the requests for the next superblock's table words -- a memory round
+// trip and the completion of the superblock's code stores waited out 1 025 times per strip.
+enum : int { kPkInAny = 0, kPkInLds = 1, kPkInHbm = 2 };
+template <int IN>
+__device__ __forceinline__ bool pk_from_lds(const bool dyn) { return IN == kPkInAny ? dyn : (IN == kPkInLds); }
+
+// Experiment switch (tools/exp): 1 = every hand-over is taken to have arrived -- no strip waits for the strip above,
+// for room in a ring or for granules.  The results are wrong; the launch's duration is what the instruction stream
+// costs without the dependency chain.
+#ifndef PSA_PK_NOSYNC
+#define PSA_PK_NOSYNC 0
+#endif
+#ifndef PSA_PK_X   // further timing-only switches: 1 no publish writes, 2 no ring reads, 4 no code stores, 8 no table loads
+#define PSA_PK_X 0
+#endif
 
 // One block of 16 steps.  D0/D1/H/V: the strip's state (named registers: see psa_batch.hip.h on why not a struct).
-template <bool CODES, int MODE>
-__device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1, int& H, int& V, const int t0, const int jb) {
+template <bool CODES, int MODE, int IN>
+__device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1, int& H, int& V, const int t0, const int jb, const int sb) {
     const int lane = c.lane;
+    const bool from_lds = pk_from_lds<IN>(c.from_lds);
     // ---- lane 0's inputs for columns t0..t0+15: ring slots t0+64..t0+79 ----
     const int slot0 = (t0 + 64) & (kRing - 1);
     const int4* rp = (const int4*)(c.my_ring + slot0) + lane;   // (only lane 0 uses what it reads, see fill_strips_v2)
-    if (c.from_lds) {
-        const int need = min(t0 + 80, c.nblocks * kBlk);
+    if (from_lds) {
+        const int need = PSA_PK_NOSYNC ? 0 : min(t0 + 80, c.nblocks * kBlk);
         if (c.prod_seen < need) {
             Spin spins;
             while (!c.dead && (c.prod_seen = __builtin_amdgcn_readfirstlane(lds_peek(&lds.prod[c.wv]))) < need) pk_expired(spins, c);
@@ -117,8 +137,8 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
     PSA_COMPILER_BARRIER();
     int4 pre[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pre[j] = rp[j];
-    if (c.from_lds) lds_post(c.cons_post, t0 + 80);
+    for (int j = 0; j < 8; ++j) pre[j] = (PSA_PK_X & 2) ? make_int4(D0, V, D1, H) : rp[j];
+    if (from_lds) lds_post(c.cons_post, t0 + 80);
     int* pa = c.out_base + (c.out_wrap ? ((2 * t0) & (c.out_wrap - 1)) : 0);
     // table words of the block, aligned to this lane's column phase
     unsigned ax[4], ay[4];
@@ -127,8 +147,21 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
         ax[q] = __builtin_amdgcn_alignbit(c.mwX[4 * jb + q + 1], c.mwX[4 * jb + q], c.msh);
         ay[q] = __builtin_amdgcn_alignbit(c.mwY[4 * jb + q + 1], c.mwY[4 * jb + q], c.msh);
     }
+    // Table words, into the registers whose words are dead (no second set, no copies): words 9..16 of THIS superblock at
+    // its block 0, words 1..8 of the NEXT one at block 2 -- each two blocks before its first use.  (A whole superblock
+    // ahead into a second set of 32 registers, as fill_strips_v2 does, did not fit beside two pairs' state: spills.)
+    if (jb == 0 || jb == 2) {
+        const int at = c.widx + (jb == 0 ? 9 : 17), to = (jb == 0 ? 9 : 1);
+        const u32x4_a4 x0 = *(const u32x4_a4*)(c.trowX + at), x1 = *(const u32x4_a4*)(c.trowX + at + 4);
+        const u32x4_a4 y0 = *(const u32x4_a4*)(c.trowY + at), y1 = *(const u32x4_a4*)(c.trowY + at + 4);
+        c.mwX[to] = x0.x; c.mwX[to + 1] = x0.y; c.mwX[to + 2] = x0.z; c.mwX[to + 3] = x0.w;
+        c.mwX[to + 4] = x1.x; c.mwX[to + 5] = x1.y; c.mwX[to + 6] = x1.z; c.mwX[to + 7] = x1.w;
+        c.mwY[to] = y0.x; c.mwY[to + 1] = y0.y; c.mwY[to + 2] = y0.z; c.mwY[to + 3] = y0.w;
+        c.mwY[to + 4] = y1.x; c.mwY[to + 5] = y1.y; c.mwY[to + 6] = y1.z; c.mwY[to + 7] = y1.w;
+    }
     const int two = 0x00020002, four = 0x00040004, eleven = 0x000b000b;
     int cd[4];
+    unsigned qx[4], qy[4];   // winner codes of the block: four steps a word
 #define PSA_PK_STEP(k, DREG)                                                                                         \
     {                                                                                                                \
         const int t = t0 + (k);                                                                                      \
@@ -149,12 +182,12 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
             if (lane == t - (c.W - 1)) { c.cap1 = x1; c.cap2 = x2; c.cap3 = x3; }                                    \
         }                                                                                                            \
         if (MODE != kPkHead || lane <= t) { DREG = D; H = Hn; V = Vn; }                                              \
-        if (((k) & 1) == 0) *(int4*)(pa + 2 * (k)) = make_int4(Dm2, Vm1, D1, V);                                     \
+        if (!(PSA_PK_X & 1) && ((k) & 1) == 0) *(int4*)(pa + 2 * (k)) = make_int4(Dm2, Vm1, D1, V);                  \
         if (CODES && ((k) & 3) == 3) {                                                                               \
             const unsigned p01 = __builtin_amdgcn_perm((unsigned)cd[1], (unsigned)cd[0], 0x06020400u);               \
             const unsigned p23 = __builtin_amdgcn_perm((unsigned)cd[3], (unsigned)cd[2], 0x06020400u);               \
-            c.qdX[4 * jb + ((k) >> 2)] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                               \
-            c.qdY[4 * jb + ((k) >> 2)] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);                               \
+            qx[(k) >> 2] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                                             \
+            qy[(k) >> 2] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);                                             \
         }                                                                                                            \
     }
     PSA_PK_STEP(0, D0) PSA_PK_STEP(1, D1) PSA_PK_STEP(2, D0) PSA_PK_STEP(3, D1)
@@ -162,6 +195,22 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
     PSA_PK_STEP(8, D0) PSA_PK_STEP(9, D1) PSA_PK_STEP(10, D0) PSA_PK_STEP(11, D1)
     PSA_PK_STEP(12, D0) PSA_PK_STEP(13, D1) PSA_PK_STEP(14, D0) PSA_PK_STEP(15, D1)
 #undef PSA_PK_STEP
+    // The block's codes leave here, 16 bytes a lane and pair (a KB per instruction), not at the superblock's end: sixteen
+    // registers a pair held across the superblock made the steady loop spill, and a spill's reload is a vector-memory
+    // operation whose wait also waits for every code store in flight.  (Uniform base + 32-bit lane offset: one
+    // address register.)
+    if (CODES && (PSA_PK_X & 4)) asm volatile("" ::"v"(qx[0]), "v"(qx[1]), "v"(qx[2]), "v"(qx[3]), "v"(qy[0]), "v"(qy[1]), "v"(qy[2]), "v"(qy[3]));
+    if (CODES && !(PSA_PK_X & 4)) {
+        const size_t at = (size_t)sb * kTileBytes + (size_t)(1024 * jb);
+        // Nontemporal: 86 GB of codes per launch of 20 pairs that nobody reads before the walk.  As plain stores they
+        // took the launch from 19 to 28-31 ms (timing-only builds without them, tools/exp): every later wait on the
+        // vector-memory counter -- the table words -- is also a wait for the stores before it, and those were slow to
+        // be acknowledged; streaming past the L2 they are acknowledged early (24 ms; the bench 3 200 -> 3 580 GCUPS).
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u vx = {qx[0], qx[1], qx[2], qx[3]}, vy = {qy[0], qy[1], qy[2], qy[3]};
+        __builtin_nontemporal_store(vx, (v4u*)(c.codesX + at + c.code_lane));
+        __builtin_nontemporal_store(vy, (v4u*)(c.codesY + at + c.code_lane));
+    }
     // the strip's last block: nobody comes to write slot 16 and the last step's D (slot 17)
     if (t0 + kBlk == c.nblocks * kBlk) {
         int* pb = c.out_base + (c.out_wrap ? ((2 * (t0 + kBlk)) & (c.out_wrap - 1)) : 0);
@@ -198,23 +247,19 @@ __device__ __forceinline__ void pk_flush(PkCtx& c, PkLds& lds, const int cb, con
     }
 }
 
-template <bool CODES, int MODE>
+template <bool CODES, int MODE, int IN>
 __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillArgs& px, const FillArgs& py, int& D0, int& D1, int& H,
                                               int& V, const int sb, const int64_t sg) {
     const int t0 = sb * 64;
     const int lane = c.lane;
-    // table words one superblock ahead (16 new words per pair)
-    const u32x4_a4 nx0 = *(const u32x4_a4*)(c.trowX + c.widx + 17), nx1 = *(const u32x4_a4*)(c.trowX + c.widx + 21);
-    const u32x4_a4 nx2 = *(const u32x4_a4*)(c.trowX + c.widx + 25), nx3 = *(const u32x4_a4*)(c.trowX + c.widx + 29);
-    const u32x4_a4 ny0 = *(const u32x4_a4*)(c.trowY + c.widx + 17), ny1 = *(const u32x4_a4*)(c.trowY + c.widx + 21);
-    const u32x4_a4 ny2 = *(const u32x4_a4*)(c.trowY + c.widx + 25), ny3 = *(const u32x4_a4*)(c.trowY + c.widx + 29);
+    const bool from_lds = pk_from_lds<IN>(c.from_lds);
     // ---- HBM out: what this strip wrote during the superblock before, still in the frame it was written in ----
     if (c.to_hbm && sb >= 2) pk_flush(c, lds, sb - 2, D0, true);
     // ---- the frame of this superblock ----
     int nbX, nbY;
-    if (c.from_lds) {
+    if (from_lds) {
         // (the producer is past its step t0 + 78, hence inside its superblock sb + 1 or beyond: that frame is published)
-        const int need = min(t0 + 80, c.nblocks * kBlk);
+        const int need = PSA_PK_NOSYNC ? 0 : min(t0 + 80, c.nblocks * kBlk);
         if (c.prod_seen < need) {
             Spin spins;
             while (!c.dead && (c.prod_seen = __builtin_amdgcn_readfirstlane(lds_peek(&lds.prod[c.wv]))) < need) pk_expired(spins, c);
@@ -235,7 +280,7 @@ __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillAr
     }
     if (c.to_lds) {
         // room in the consumer's ring for the slots this superblock writes (up to t0 + 65)
-        const int need = t0 + 66 - kRing;
+        const int need = PSA_PK_NOSYNC ? -(1 << 30) : t0 + 66 - kRing;
         if (c.cons_seen < need) {
             Spin spins;
             while (!c.dead && (c.cons_seen = __builtin_amdgcn_readfirstlane(lds_peek(&lds.cons[c.wv + 1]))) < need) pk_expired(spins, c);
@@ -250,7 +295,7 @@ __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillAr
         }
     }
     // ---- first strip of a workgroup: the row above, 64 columns, from HBM granules (or the matrix's row 0) ----
-    if (!c.from_lds) {
+    if (!from_lds) {
         int dX, vX, dY, vY;
         const int col = t0 + lane;
         if (c.top) {
@@ -262,13 +307,13 @@ __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillAr
         } else {
             u64 gx = c.gbX, gy = c.gbY;
             const int cc = min(col, c.W - 1);
-            if (!__all((gx >> 32) == c.tag_in && (gy >> 32) == c.tag_in)) {
+            if (!PSA_PK_NOSYNC && !__all((gx >> 32) == c.tag_in && (gy >> 32) == c.tag_in)) {
                 Spin spins;
                 do {
                     pk_expired(spins, c);
                     gx = load_granule(c.ginX + cc);
                     gy = load_granule(c.ginY + cc);
-                } while (!c.dead && !__all((gx >> 32) == c.tag_in && (gy >> 32) == c.tag_in));
+                } while (!__all((gx >> 32) == c.tag_in && (gy >> 32) == c.tag_in) && !c.dead);   // (the tags first: no load in flight on any way out)
             }
             const int cn = min(col + 64, c.W - 1);
             c.gbX = load_granule(c.ginX + cn);
@@ -278,39 +323,19 @@ __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillAr
         }
         pk_feed_ring(c, t0, dX, vX, dY, vY);
         if (sb == 0 && lane == 0)   // its input has arrived: move the front (see fill_strips_v2's prologue)
-            __hip_atomic_fetch_max(px.ticket + kFrontWord, (unsigned)(sg / kNW) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(px.ticket + kFrontWord, (unsigned)(sg / kPkNW) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    pk_block<CODES, MODE>(c, lds, D0, D1, H, V, t0, 0);
-    pk_block<CODES, MODE>(c, lds, D0, D1, H, V, t0 + 16, 1);
-    pk_block<CODES, MODE>(c, lds, D0, D1, H, V, t0 + 32, 2);
-    pk_block<CODES, MODE>(c, lds, D0, D1, H, V, t0 + 48, 3);
-    if (CODES) {
-        uint4* dx = (uint4*)(c.codesX + (size_t)sb * kTileBytes);
-        uint4* dy = (uint4*)(c.codesY + (size_t)sb * kTileBytes);
-        dx[0] = make_uint4(c.qdX[0], c.qdX[1], c.qdX[2], c.qdX[3]);
-        dy[0] = make_uint4(c.qdY[0], c.qdY[1], c.qdY[2], c.qdY[3]);
-        dx[64] = make_uint4(c.qdX[4], c.qdX[5], c.qdX[6], c.qdX[7]);
-        dy[64] = make_uint4(c.qdY[4], c.qdY[5], c.qdY[6], c.qdY[7]);
-        dx[128] = make_uint4(c.qdX[8], c.qdX[9], c.qdX[10], c.qdX[11]);
-        dy[128] = make_uint4(c.qdY[8], c.qdY[9], c.qdY[10], c.qdY[11]);
-        dx[192] = make_uint4(c.qdX[12], c.qdX[13], c.qdX[14], c.qdX[15]);
-        dy[192] = make_uint4(c.qdY[12], c.qdY[13], c.qdY[14], c.qdY[15]);
-    }
+    pk_block<CODES, MODE, IN>(c, lds, D0, D1, H, V, t0, 0, sb);
+    pk_block<CODES, MODE, IN>(c, lds, D0, D1, H, V, t0 + 16, 1, sb);
+    pk_block<CODES, MODE, IN>(c, lds, D0, D1, H, V, t0 + 32, 2, sb);
+    pk_block<CODES, MODE, IN>(c, lds, D0, D1, H, V, t0 + 48, 3, sb);
     if (MODE == kPkTail) {
         // lanes that passed column W-1 in this superblock: their capture is in this superblock's frame
         const int ts = c.W - 1 + lane;
         if (ts >= t0 && ts < t0 + 64) { c.capBX = c.baseX; c.capBY = c.baseY; }
     }
     c.mwX[0] = c.mwX[16];
-    c.mwX[1] = nx0.x; c.mwX[2] = nx0.y; c.mwX[3] = nx0.z; c.mwX[4] = nx0.w;
-    c.mwX[5] = nx1.x; c.mwX[6] = nx1.y; c.mwX[7] = nx1.z; c.mwX[8] = nx1.w;
-    c.mwX[9] = nx2.x; c.mwX[10] = nx2.y; c.mwX[11] = nx2.z; c.mwX[12] = nx2.w;
-    c.mwX[13] = nx3.x; c.mwX[14] = nx3.y; c.mwX[15] = nx3.z; c.mwX[16] = nx3.w;
     c.mwY[0] = c.mwY[16];
-    c.mwY[1] = ny0.x; c.mwY[2] = ny0.y; c.mwY[3] = ny0.z; c.mwY[4] = ny0.w;
-    c.mwY[5] = ny1.x; c.mwY[6] = ny1.y; c.mwY[7] = ny1.z; c.mwY[8] = ny1.w;
-    c.mwY[9] = ny2.x; c.mwY[10] = ny2.y; c.mwY[11] = ny2.z; c.mwY[12] = ny2.w;
-    c.mwY[13] = ny3.x; c.mwY[14] = ny3.y; c.mwY[15] = ny3.z; c.mwY[16] = ny3.w;
     c.widx += 16;
 }
 
@@ -323,14 +348,18 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     extern __shared__ unsigned lds_keepout[];
     PkCtx c;
     const int lane = c.lane = threadIdx.x & 63;
-    const int wv = c.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hw_wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x == 0) wg_ticket = atomicAdd(B.ticket, 1u);
-    if (threadIdx.x < kNW) { lds.prod[threadIdx.x] = 0; lds.cons[threadIdx.x] = 0; }
+    if (threadIdx.x < kPkNW) { lds.prod[threadIdx.x] = 0; lds.cons[threadIdx.x] = 0; }
     __syncthreads();
     const unsigned tk = __builtin_amdgcn_readfirstlane(wg_ticket);
     const unsigned og = B.order ? __builtin_amdgcn_readfirstlane(B.order[tk]) : tk;
     const unsigned group = og & ((1u << kOrderJobShift) - 1);
     const unsigned couple = og >> kOrderJobShift;
+    // (strip = wavefront number.  Taking turns -- strip (wavefront + workgroup) mod 4, so that the strips that do more
+    // than the others, the first and the last of a workgroup, are not always the same wavefront of a CU -- was measured:
+    // 3 139 against 3 160-3 210 GCUPS.)
+    const int wv = c.wv = hw_wv;
     const FillArgs2& qx = B.job[2 * couple];
     const FillArgs2& qy = B.job[2 * couple + 1];
     const FillArgs& px = qx.base;
@@ -338,7 +367,7 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     if (px.W < 0) lds_keepout[threadIdx.x] = group;   // (never true; keeps the dynamic LDS referenced)
     const int64_t n = px.n;
     const int64_t strips = (n + 63) >> 6;
-    const int64_t sg = (int64_t)group * kNW + wv;
+    const int64_t sg = (int64_t)group * kPkNW + wv;
     if (sg >= strips) return;
     const int64_t i = 64 * sg + lane + 1;
     const bool row_ok = i <= n;
@@ -346,7 +375,7 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     c.Q = px.Q;
     c.nblocks = px.Q * (64 / kBlk);
     const bool last = (sg == strips - 1);
-    c.to_lds = (wv + 1 < kNW) && !last;
+    c.to_lds = (wv + 1 < kPkNW) && !last;
     c.to_hbm = !c.to_lds && !last;
     c.from_lds = wv > 0;
     c.top = (sg == 0);
@@ -365,8 +394,6 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     int D0 = pk_pair(D_own - c.baseX, D_own - c.baseY), D1 = D0;
     int H = pk_pair(H_own - c.baseX, H_own - c.baseY);
     int V = 0;
-    c.cap1 = c.cap2 = c.cap3 = 0;
-    c.capBX = c.capBY = 0;
     c.carryX = c.carryY = D_up;   // (lane 0's: D of the row above at column 0)
 
     // ---- substitution table rows of this lane in both pairs ----
@@ -378,8 +405,9 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     c.widx = (-lane - ((64 - lane) & 3)) / 4;
 #pragma unroll
     for (int j = 0; j < 17; ++j) { c.mwX[j] = c.trowX[c.widx + j]; c.mwY[j] = c.trowY[c.widx + j]; }
-    c.codesX = CODES ? px.codes + code_tile_offset(sg, px.Q, 0) + 16 * lane : nullptr;
-    c.codesY = CODES ? py.codes + code_tile_offset(sg, px.Q, 0) + 16 * lane : nullptr;
+    c.codesX = CODES ? px.codes + code_tile_offset(sg, px.Q, 0) : nullptr;
+    c.codesY = CODES ? py.codes + code_tile_offset(sg, px.Q, 0) : nullptr;
+    c.code_lane = 16u * (unsigned)lane;
     c.prod_seen = 0;
     c.cons_seen = 0;
 
@@ -392,14 +420,14 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     c.cons_post = (lane == 0 && c.from_lds) ? &lds.cons[wv] : &lds.dummy2[wv][lane];
     c.tag_in = (u64)sg;
     c.tag_out = (u64)(sg + 1);
-    c.ginX = px.ring + (size_t)(((sg - 1) / kNW) & 1) * px.Wpad;
-    c.ginY = py.ring + (size_t)(((sg - 1) / kNW) & 1) * py.Wpad;
-    c.goutX = px.ring + (size_t)((sg / kNW) & 1) * px.Wpad;
-    c.goutY = py.ring + (size_t)((sg / kNW) & 1) * py.Wpad;
+    c.ginX = px.ring + (size_t)(((sg - 1) / kPkNW) & 1) * px.Wpad;
+    c.ginY = py.ring + (size_t)(((sg - 1) / kPkNW) & 1) * py.Wpad;
+    c.goutX = px.ring + (size_t)((sg / kPkNW) & 1) * px.Wpad;
+    c.goutY = py.ring + (size_t)((sg / kPkNW) & 1) * py.Wpad;
     c.gbX = c.gbY = 0;
 
     // a workgroup far down the chain sleeps on the chain's front first (see fill_strips_v2)
-    if (wv == 0 && group >= 2) {
+    if (!PSA_PK_NOSYNC && wv == 0 && group >= 2) {
         Spin spins;
         for (;;) {
             const unsigned f = __builtin_amdgcn_readfirstlane(
@@ -428,11 +456,18 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     // column W-1, capturing
     const int Q = c.Q;
     const int capture_lo = last ? (W - 1) / 64 : Q;
-    pk_superblock<CODES, kPkHead>(c, lds, px, py, D0, D1, H, V, 0, sg);
-    for (int sb = 1; sb < capture_lo; ++sb)
-        pk_superblock<CODES, kPkFast>(c, lds, px, py, D0, D1, H, V, sb, sg);
+    pk_superblock<CODES, kPkHead, kPkInAny>(c, lds, px, py, D0, D1, H, V, 0, sg);
+    if (c.from_lds) {
+        for (int sb = 1; sb < capture_lo; ++sb)
+            pk_superblock<CODES, kPkFast, kPkInLds>(c, lds, px, py, D0, D1, H, V, sb, sg);
+    } else {
+        for (int sb = 1; sb < capture_lo; ++sb)
+            pk_superblock<CODES, kPkFast, kPkInHbm>(c, lds, px, py, D0, D1, H, V, sb, sg);
+    }
+    c.cap1 = c.cap2 = c.cap3 = 0;   // (set here, not before the steady loop: five registers it does not have to carry)
+    c.capBX = c.capBY = 0;
     for (int sb = capture_lo < 1 ? 1 : capture_lo; sb < Q; ++sb)
-        pk_superblock<CODES, kPkTail>(c, lds, px, py, D0, D1, H, V, sb, sg);
+        pk_superblock<CODES, kPkTail, kPkInAny>(c, lds, px, py, D0, D1, H, V, sb, sg);
 
     if (c.to_hbm) {
         if (Q >= 2) pk_flush(c, lds, Q - 2, D0, false);
@@ -459,7 +494,7 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
 #define PSA_PK_WAVES 3
 #endif
 template <bool CODES>
-__global__ __launch_bounds__(kNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_PK_WAVES, PSA_PK_WAVES))) void fill_strips_pk(FillBatch B) {
+__global__ __launch_bounds__(kPkNW * 64) __attribute__((amdgpu_waves_per_eu(PSA_PK_WAVES, PSA_PK_WAVES))) void fill_strips_pk(FillBatch B) {
     fill_pk_body<CODES>(B);
 }
 

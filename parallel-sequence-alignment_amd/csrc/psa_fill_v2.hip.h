@@ -466,11 +466,16 @@ __device__ __forceinline__ bool run_superblock(StripCtx<CODES>& c, FillLds& lds,
     PSA_BLOCK(3)
 #undef PSA_BLOCK
     if (CODES) {
-        uint4* dst = (uint4*)(p.codes + code_tile_offset(c.sg, p.Q, sb)) + c.lane;
-        dst[0] = make_uint4(c.qd[0], c.qd[1], c.qd[2], c.qd[3]);
-        dst[64] = make_uint4(c.qd[4], c.qd[5], c.qd[6], c.qd[7]);
-        dst[128] = make_uint4(c.qd[8], c.qd[9], c.qd[10], c.qd[11]);
-        dst[192] = make_uint4(c.qd[12], c.qd[13], c.qd[14], c.qd[15]);
+        // (nontemporal: nobody reads the codes before the walk, and plain stores are slow to be acknowledged, which every
+        // later wait on the vector-memory counter then pays for -- see psa_fill_pk.hip.h)
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        v4u* dst = (v4u*)(p.codes + code_tile_offset(c.sg, p.Q, sb)) + c.lane;
+        const v4u q0 = {c.qd[0], c.qd[1], c.qd[2], c.qd[3]}, q1 = {c.qd[4], c.qd[5], c.qd[6], c.qd[7]};
+        const v4u q2 = {c.qd[8], c.qd[9], c.qd[10], c.qd[11]}, q3 = {c.qd[12], c.qd[13], c.qd[14], c.qd[15]};
+        __builtin_nontemporal_store(q0, dst);
+        __builtin_nontemporal_store(q1, dst + 64);
+        __builtin_nontemporal_store(q2, dst + 128);
+        __builtin_nontemporal_store(q3, dst + 192);
     }
     c.mw[0] = c.mw[16];
     c.mw[1] = n0.x; c.mw[2] = n0.y; c.mw[3] = n0.z; c.mw[4] = n0.w;

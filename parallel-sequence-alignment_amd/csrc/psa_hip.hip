@@ -1569,7 +1569,8 @@ int psa_many_launch_after(psa_many* e, psa_many* after) {
         unsigned cgroups[psa::kMaxJobs], ctotal = 0, crounds = 0;
         for (int x = 0; x < npk; ++x) fb.job[x] = jobs[pk_of[x]];
         for (int cidx = 0; cidx < nc; ++cidx) {
-            cgroups[cidx] = groups[pk_of[2 * cidx]];
+            const psa::FillArgs& fx = jobs[pk_of[2 * cidx]].base;   // (workgroups of kPkNW strips there)
+            cgroups[cidx] = (unsigned)(((fx.r1 - fx.r0 + 63) / 64 + psa::kPkNW - 1) / psa::kPkNW);
             ctotal += cgroups[cidx];
             crounds = std::max(crounds, cgroups[cidx]);
         }

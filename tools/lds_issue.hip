@@ -13,7 +13,7 @@
   X(7, "ds_read_b128 %13, %8", "ds_read_b128 (never waited for)") \
   X(8, "ds_write_b8 %8, %0", "ds_write_b8") \
   X(9, "ds_write_b16 %8, %0", "ds_write_b16")
-template <int KIND, bool ONE_LANE>
+template <int KIND, bool ONE_LANE, bool MASKED = false>
 __global__ __launch_bounds__(256) void k(int* out, int iters, int seed) {
     __shared__ int dump[4][1024];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -25,11 +25,18 @@ __global__ __launch_bounds__(256) void k(int* out, int iters, int seed) {
     typedef int v4i __attribute__((ext_vector_type(4)));
     v4i p128 = {seed, 1, 2, 3}, r128 = {0, 0, 0, 0};
     int r32 = 0;
+    const unsigned long long lane63 = 1ull << 63;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
 #define ONE(id, txt, name)                                                                                                    \
-    if (KIND == id)                                                                                                           \
+    if (KIND == id && MASKED)                                                                                                 \
+        asm volatile("v_add_u32_e32 %0, %7, %0\n v_max_i32_e32 %1, %7, %1\n v_add_u32_e32 %2, %7, %2\n s_mov_b64 exec, %14\n" txt \
+                     "\n s_mov_b64 exec, -1\n v_max_i32_e32 %3, %7, %3\n v_add_u32_e32 %4, %7, %4\n v_max_i32_e32 %5, %7, %5" \
+                     : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(r32)                                  \
+                     : "v"(w), "v"(addr), "v"(r32), "v"(p64), "v"(p128), "v"(q64), "v"(r128), "s"(lane63)                     \
+                     : "memory");                                                                                             \
+    if (KIND == id && !MASKED)                                                                                                \
         asm volatile("v_add_u32_e32 %0, %7, %0\n v_max_i32_e32 %1, %7, %1\n v_add_u32_e32 %2, %7, %2\n" txt                  \
                      "\n v_max_i32_e32 %3, %7, %3\n v_add_u32_e32 %4, %7, %4\n v_max_i32_e32 %5, %7, %5"                      \
                      : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(r32)                                  \
@@ -42,18 +49,18 @@ __global__ __launch_bounds__(256) void k(int* out, int iters, int seed) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if ((v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5) == 0x7fffffff) out[0] = r32 + r128.x;
 }
-template <int KIND, bool ONE_LANE = false>
+template <int KIND, bool ONE_LANE = false, bool MASKED = false>
 void run(const char* name, int cus, int* out) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
     printf("%-34s", name);
-    for (int wps : {1, 2}) {
+    for (int wps : {1, 2, 3}) {
         dim3 grid(cus * wps), block(256);
         float ms = 0;
         for (int rep = 0; rep < 2; ++rep) {
             hipEventRecord(e0);
-            hipLaunchKernelGGL((k<KIND, ONE_LANE>), grid, block, 0, 0, out, iters, rep);
+            hipLaunchKernelGGL((k<KIND, ONE_LANE, MASKED>), grid, block, 0, 0, out, iters, rep);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
@@ -74,5 +81,8 @@ int main() {
     printf("all lanes on one address:\n");
 #define RUN1(id, txt, name) run<id, true>(name, cus, out);
     KINDS(RUN1)
+    printf("exec = lane 63 only around the LDS instruction (two s_mov_b64 more per group):\n");
+#define RUNM(id, txt, name) run<id, false, true>(name, cus, out);
+    KINDS(RUNM)
     return 0;
 }
