@@ -430,7 +430,7 @@ def single_gpu(args):
                    "parallelism": "independent pairs per GPU" if world > 1 else "one GPU"},
         "roofline": {"bound": "valu",
                      "kernel": ("%s: ONE launch filling %d pairs (winner codes on), %s" % (
-                         kname, per_launch_pairs, "two pairs per lane in packed 16-bit halves, two wavefronts per SIMD" if packed
+                         kname, per_launch_pairs, "two pairs per lane in packed 16-bit halves, three wavefronts per SIMD" if packed
                          else "two wavefronts per SIMD")) if per_launch_pairs > 1
                      else "fill_strips_v2<true>: one pair per launch (winner codes on), one wavefront per SIMD",
                      "achieved": achieved, "peak": peak, "unit": "T 16-bit lane operations / s" if packed else "Tint32op/s",
