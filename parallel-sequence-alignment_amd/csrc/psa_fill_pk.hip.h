@@ -115,9 +115,33 @@ __device__ __forceinline__ bool pk_from_lds(const bool dyn) { return IN == kPkIn
 #ifndef PSA_PK_NOSYNC
 #define PSA_PK_NOSYNC 0
 #endif
-#ifndef PSA_PK_X   // further timing-only switches: 1 no publish writes, 2 no ring reads, 4 no code stores, 8 no table loads
+#ifndef PSA_PK_X   // further timing-only switches: 1 no publish writes, 2 no ring reads, 4 no code stores, 8 no table loads (the first words stay)
 #define PSA_PK_X 0
 #endif
+
+// Lane 63's 16 bytes into the next strip's ring.  PSA_PK_MASKED bit 0: under an execution mask of lane 63 alone (two
+// scalar moves around the instruction) instead of every lane writing its 16 bytes somewhere.  The LDS takes as long for
+// the instruction either way (tools/exp/lds_tp.hip: 14 cycles), but the launch is held back by the device's power
+// management, not by issue slots -- the same instruction stream ran at 2.15 GHz without the code stores and at 1.77 GHz
+// with them (SQ_BUSY_CYCLES over the launch's duration, timing-only builds) -- and 63 lanes' worth of data that does not
+// move is power: 3 630 -> 3 750 GCUPS.  Bit 1, the same for the ring reads (lane 0 alone; hand-placed waits, the
+// compiler does not see LDS operations inside asm): 3 690, off.
+#ifndef PSA_PK_MASKED
+#define PSA_PK_MASKED 1
+#endif
+template <int OFF>
+__device__ __forceinline__ void pk_publish(int* pa, const int4 v) {
+#if PSA_PK_MASKED
+    // only lane 63 writes (the execution mask around the instruction: two scalar moves; the LDS takes as long, but 63
+    // lanes' worth of data does not move)
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const unsigned a = (unsigned)(size_t)pa;
+    const v4i w = {v.x, v.y, v.z, v.w};
+    asm volatile("s_mov_b64 exec, %2\n\tds_write_b128 %0, %1 offset:%3\n\ts_mov_b64 exec, -1" ::"v"(a), "v"(w), "s"(1ull << 63), "i"(OFF) : "memory");
+#else
+    *(int4*)(pa + OFF / 4) = v;
+#endif
+}
 
 // One block of 16 steps.  D0/D1/H/V: the strip's state (named registers: see psa_batch.hip.h on why not a struct).
 template <bool CODES, int MODE, int IN>
@@ -136,8 +160,30 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
     }
     PSA_COMPILER_BARRIER();
     int4 pre[8];
+#if PSA_PK_MASKED & 2
+    {
+        // only lane 0 reads (its execution mask around the eight reads); the compiler does not see these LDS operations,
+        // so the waits are placed by hand (PK_PRE_READY below)
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        v4i r0, r1, r2, r3, r4, r5, r6, r7;
+        const unsigned ra = (unsigned)(size_t)(c.my_ring + slot0);
+        asm volatile("s_mov_b64 exec, 1\n\tds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
+                     "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
+                     "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_mov_b64 exec, -1"
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(ra) : "memory");
+        pre[0] = make_int4(r0.x, r0.y, r0.z, r0.w); pre[1] = make_int4(r1.x, r1.y, r1.z, r1.w);
+        pre[2] = make_int4(r2.x, r2.y, r2.z, r2.w); pre[3] = make_int4(r3.x, r3.y, r3.z, r3.w);
+        pre[4] = make_int4(r4.x, r4.y, r4.z, r4.w); pre[5] = make_int4(r5.x, r5.y, r5.z, r5.w);
+        pre[6] = make_int4(r6.x, r6.y, r6.z, r6.w); pre[7] = make_int4(r7.x, r7.y, r7.z, r7.w);
+    }
+    // before the first use of pre[j] (step 2j): the LDS operations issued after its read are the 7 - j reads behind it,
+    // the consumer's counter post and the j publish writes of the steps so far -- never fewer than 7
+#define PK_PRE_READY(j) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(pre[j].x), "+v"(pre[j].y), "+v"(pre[j].z), "+v"(pre[j].w))
+#else
 #pragma unroll
     for (int j = 0; j < 8; ++j) pre[j] = (PSA_PK_X & 2) ? make_int4(D0, V, D1, H) : rp[j];
+#define PK_PRE_READY(j)
+#endif
     if (from_lds) lds_post(c.cons_post, t0 + 80);
     int* pa = c.out_base + (c.out_wrap ? ((2 * t0) & (c.out_wrap - 1)) : 0);
     // table words of the block, aligned to this lane's column phase
@@ -150,7 +196,7 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
     // Table words, into the registers whose words are dead (no second set, no copies): words 9..16 of THIS superblock at
     // its block 0, words 1..8 of the NEXT one at block 2 -- each two blocks before its first use.  (A whole superblock
     // ahead into a second set of 32 registers, as fill_strips_v2 does, did not fit beside two pairs' state: spills.)
-    if (jb == 0 || jb == 2) {
+    if (!(PSA_PK_X & 8) && (jb == 0 || jb == 2)) {
         const int at = c.widx + (jb == 0 ? 9 : 17), to = (jb == 0 ? 9 : 1);
         const u32x4_a4 x0 = *(const u32x4_a4*)(c.trowX + at), x1 = *(const u32x4_a4*)(c.trowX + at + 4);
         const u32x4_a4 y0 = *(const u32x4_a4*)(c.trowY + at), y1 = *(const u32x4_a4*)(c.trowY + at + 4);
@@ -165,6 +211,7 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
 #define PSA_PK_STEP(k, DREG)                                                                                         \
     {                                                                                                                \
         const int t = t0 + (k);                                                                                      \
+        if (((k) & 1) == 0) { PK_PRE_READY((k) >> 1); }                                                              \
         const int preD = ((k) & 1) ? pre[(k) >> 1].z : pre[(k) >> 1].x;                                              \
         const int preV = ((k) & 1) ? pre[(k) >> 1].w : pre[(k) >> 1].y;                                              \
         const int Dm2 = D0, Vm1 = V;                                                                                 \
@@ -182,7 +229,7 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
             if (lane == t - (c.W - 1)) { c.cap1 = x1; c.cap2 = x2; c.cap3 = x3; }                                    \
         }                                                                                                            \
         if (MODE != kPkHead || lane <= t) { DREG = D; H = Hn; V = Vn; }                                              \
-        if (!(PSA_PK_X & 1) && ((k) & 1) == 0) *(int4*)(pa + 2 * (k)) = make_int4(Dm2, Vm1, D1, V);                  \
+        if (!(PSA_PK_X & 1) && ((k) & 1) == 0) pk_publish<8 * (k)>(pa, make_int4(Dm2, Vm1, D1, V));                  \
         if (CODES && ((k) & 3) == 3) {                                                                               \
             const unsigned p01 = __builtin_amdgcn_perm((unsigned)cd[1], (unsigned)cd[0], 0x06020400u);               \
             const unsigned p23 = __builtin_amdgcn_perm((unsigned)cd[3], (unsigned)cd[2], 0x06020400u);               \
@@ -195,6 +242,7 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
     PSA_PK_STEP(8, D0) PSA_PK_STEP(9, D1) PSA_PK_STEP(10, D0) PSA_PK_STEP(11, D1)
     PSA_PK_STEP(12, D0) PSA_PK_STEP(13, D1) PSA_PK_STEP(14, D0) PSA_PK_STEP(15, D1)
 #undef PSA_PK_STEP
+#undef PK_PRE_READY
     // The block's codes leave here, 16 bytes a lane and pair (a KB per instruction), not at the superblock's end: sixteen
     // registers a pair held across the superblock made the steady loop spill, and a spill's reload is a vector-memory
     // operation whose wait also waits for every code store in flight.  (Uniform base + 32-bit lane offset: one
@@ -316,8 +364,10 @@ __device__ __forceinline__ void pk_superblock(PkCtx& c, PkLds& lds, const FillAr
                 } while (!__all((gx >> 32) == c.tag_in && (gy >> 32) == c.tag_in) && !c.dead);   // (the tags first: no load in flight on any way out)
             }
             const int cn = min(col + 64, c.W - 1);
-            c.gbX = load_granule(c.ginX + cn);
-            c.gbY = load_granule(c.ginY + cn);
+            if (!(PSA_PK_X & 32)) {   // (32: timing only, the first strip of a workgroup requests no granules)
+                c.gbX = load_granule(c.ginX + cn);
+                c.gbY = load_granule(c.ginY + cn);
+            }
             dX = (int)((unsigned)gx >> 2); vX = dX + (int)((unsigned)gx & 3u);
             dY = (int)((unsigned)gy >> 2); vY = dY + (int)((unsigned)gy & 3u);
         }
