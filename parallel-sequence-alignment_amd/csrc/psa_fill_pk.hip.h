@@ -124,10 +124,11 @@ __device__ __forceinline__ bool pk_from_lds(const bool dyn) { return IN == kPkIn
 // the instruction either way (tools/exp/lds_tp.hip: 14 cycles), but the launch is held back by the device's power
 // management, not by issue slots -- the same instruction stream ran at 2.15 GHz without the code stores and at 1.77 GHz
 // with them (SQ_BUSY_CYCLES over the launch's duration, timing-only builds) -- and 63 lanes' worth of data that does not
-// move is power: 3 630 -> 3 750 GCUPS.  Bit 1, the same for the ring reads (lane 0 alone; hand-placed waits, the
-// compiler does not see LDS operations inside asm): 3 690, off.
+// move is power: 3 630 -> 3 690-3 750 GCUPS.  Bit 1, the same for the ring reads, lane 0 alone, as a divergent region
+// of the compiler's own making (3 770; with the mask set by hand inside asm the compiler does not see the LDS
+// operations and the hand-placed waits cost what the lanes saved: 3 690).
 #ifndef PSA_PK_MASKED
-#define PSA_PK_MASKED 1
+#define PSA_PK_MASKED 3
 #endif
 template <int OFF>
 __device__ __forceinline__ void pk_publish(int* pa, const int4 v) {
@@ -161,24 +162,13 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
     PSA_COMPILER_BARRIER();
     int4 pre[8];
 #if PSA_PK_MASKED & 2
-    {
-        // only lane 0 reads (its execution mask around the eight reads); the compiler does not see these LDS operations,
-        // so the waits are placed by hand (PK_PRE_READY below)
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        v4i r0, r1, r2, r3, r4, r5, r6, r7;
-        const unsigned ra = (unsigned)(size_t)(c.my_ring + slot0);
-        asm volatile("s_mov_b64 exec, 1\n\tds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:32\n\t"
-                     "ds_read_b128 %3, %8 offset:48\n\tds_read_b128 %4, %8 offset:64\n\tds_read_b128 %5, %8 offset:80\n\t"
-                     "ds_read_b128 %6, %8 offset:96\n\tds_read_b128 %7, %8 offset:112\n\ts_mov_b64 exec, -1"
-                     : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7) : "v"(ra) : "memory");
-        pre[0] = make_int4(r0.x, r0.y, r0.z, r0.w); pre[1] = make_int4(r1.x, r1.y, r1.z, r1.w);
-        pre[2] = make_int4(r2.x, r2.y, r2.z, r2.w); pre[3] = make_int4(r3.x, r3.y, r3.z, r3.w);
-        pre[4] = make_int4(r4.x, r4.y, r4.z, r4.w); pre[5] = make_int4(r5.x, r5.y, r5.z, r5.w);
-        pre[6] = make_int4(r6.x, r6.y, r6.z, r6.w); pre[7] = make_int4(r7.x, r7.y, r7.z, r7.w);
+    // only lane 0 reads (a divergent region the compiler builds itself, so that its waits stay counted ones; the other
+    // lanes' registers are never looked at: the DPP moves overwrite them)
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pre[j] = rp[j];
     }
-    // before the first use of pre[j] (step 2j): the LDS operations issued after its read are the 7 - j reads behind it,
-    // the consumer's counter post and the j publish writes of the steps so far -- never fewer than 7
-#define PK_PRE_READY(j) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(pre[j].x), "+v"(pre[j].y), "+v"(pre[j].z), "+v"(pre[j].w))
+#define PK_PRE_READY(j)
 #else
 #pragma unroll
     for (int j = 0; j < 8; ++j) pre[j] = (PSA_PK_X & 2) ? make_int4(D0, V, D1, H) : rp[j];
