@@ -109,7 +109,7 @@ enum : int { kPkInAny = 0, kPkInLds = 1, kPkInHbm = 2 };
 template <int IN>
 __device__ __forceinline__ bool pk_from_lds(const bool dyn) { return IN == kPkInAny ? dyn : (IN == kPkInLds); }
 
-// Experiment switch (tools/exp): 1 = every hand-over is taken to have arrived -- no strip waits for the strip above,
+// Experiment switch (tools/x_sweep.sh): 1 = every hand-over is taken to have arrived -- no strip waits for the strip above,
 // for room in a ring or for granules.  The results are wrong; the launch's duration is what the instruction stream
 // costs without the dependency chain.
 #ifndef PSA_PK_NOSYNC
@@ -121,7 +121,7 @@ __device__ __forceinline__ bool pk_from_lds(const bool dyn) { return IN == kPkIn
 
 // Lane 63's 16 bytes into the next strip's ring.  PSA_PK_MASKED bit 0: under an execution mask of lane 63 alone (two
 // scalar moves around the instruction) instead of every lane writing its 16 bytes somewhere.  The LDS takes as long for
-// the instruction either way (tools/exp/lds_tp.hip: 14 cycles), but the launch is held back by the device's power
+// the instruction either way (tools/lds_tp.hip: 14 cycles), but the launch is held back by the device's power
 // management, not by issue slots -- the same instruction stream ran at 2.15 GHz without the code stores and at 1.77 GHz
 // with them (SQ_BUSY_CYCLES over the launch's duration, timing-only builds) -- and 63 lanes' worth of data that does not
 // move is power: 3 630 -> 3 690-3 750 GCUPS.  Bit 1, the same for the ring reads, lane 0 alone, as a divergent region
@@ -241,7 +241,7 @@ __device__ __forceinline__ void pk_block(PkCtx& c, PkLds& lds, int& D0, int& D1,
     if (CODES && !(PSA_PK_X & 4)) {
         const size_t at = (size_t)sb * kTileBytes + (size_t)(1024 * jb);
         // Nontemporal: 86 GB of codes per launch of 20 pairs that nobody reads before the walk.  As plain stores they
-        // took the launch from 19 to 28-31 ms (timing-only builds without them, tools/exp): every later wait on the
+        // took the launch from 19 to 28-31 ms (timing-only builds without them, tools/x_sweep.sh): every later wait on the
         // vector-memory counter -- the table words -- is also a wait for the stores before it, and those were slow to
         // be acknowledged; streaming past the L2 they are acknowledged early (24 ms; the bench 3 200 -> 3 580 GCUPS).
         typedef unsigned v4u __attribute__((ext_vector_type(4)));
