@@ -25,6 +25,7 @@ $(OBJDIR)/psa_batch.o: $(CS)/psa_batch.hip $(CS)/psa_batch.hip.h $(COMMON)
 
 PKWAVES ?= 3
 $(OBJDIR)/psa_fill_pk.o: HIPFLAGS += -DPSA_PK_WAVES=$(PKWAVES) $(PKEXTRA)
+$(OBJDIR)/psa_trace.o: HIPFLAGS += $(TBEXTRA)
 # (strips per workgroup of the packed kernel: host and kernel must agree, so for every object)
 ifdef PKNW
 HIPFLAGS += -DPSA_PK_NW=$(PKNW)
