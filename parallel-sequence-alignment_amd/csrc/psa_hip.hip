@@ -499,7 +499,7 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
     DeviceGuard g(s->device);
     if (g.rc) return g.rc;
     if (int rc = check_abort(s, st)) return rc;
-    int64_t state[12] = {*i_io, *j_io, *k_io, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t state[16] = {*i_io, *j_io, *k_io, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(s->tb_state, state, sizeof state, hipMemcpyHostToDevice, st));
     psa::TraceArgs ta;
     if (int rc = make_trace_args(s, o, &ta)) return rc;
@@ -519,6 +519,8 @@ int traceback_impl(psa_stripe* s, int64_t* i_io, int64_t* j_io, int* k_io, int32
                 (long long)(state[6] >> 32), (long long)(state[6] & 0xffffffff), (long long)(state[7] >> 32), (long long)(state[7] & 0xffffffff));
         fprintf(stderr, "traceback: core cycles %lld, 100 MHz ticks %lld (the counts above need a -DPSA_TB_STATS build; fetcher: blocked %lld rounds %lld operations %lld)\n", (long long)state[8], (long long)state[9],
                 (long long)(state[10] >> 32), (long long)(state[10] & 0xffffffff), (long long)state[11]);
+        fprintf(stderr, "traceback: one-cell steps by what bounded the rectangle: row above %lld, column to the left %lld, the diagonal's own length %lld\n",
+                (long long)state[12], (long long)state[13], (long long)state[14]);
     }
     if (state[5] == 2) return fail(PSA_E_KERNEL, "traceback: winner codes failed the decode check (values that cannot belong to one cell)");
     if (state[5] == 3) return fail(PSA_E_KERNEL, "traceback: the walk waited in vain for a code tile (fetching wavefront stalled)");

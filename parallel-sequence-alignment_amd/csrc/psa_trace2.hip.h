@@ -214,7 +214,7 @@ __device__ __forceinline__ void t2_walker(const TraceArgs& p, uint8_t* lds) {
     int rlo = 0x7fffffff, ulo = 0x7fffffff;
     int rowfloor1 = 0, ufloor = 0;
 #ifdef PSA_TB_STATS
-    int n_iter = 0, n_miss = 0, n_tiles = 0, n_single = 0;
+    int n_iter = 0, n_miss = 0, n_tiles = 0, n_single = 0, n_c_row = 0, n_c_left = 0, n_c_len = 0;
 #endif
     const long long tc0 = (long long)__builtin_readcyclecounter(), tw0 = (long long)wall_clock64();
     const unsigned lane2h = (unsigned)(2 * lane) << 24;
@@ -295,6 +295,9 @@ __device__ __forceinline__ void t2_walker(const TraceArgs& p, uint8_t* lds) {
             // ---- one pass (as in tb_walk) ----
             const int dmax = tb_smin(tb_smin(kTbPassLanes - 1, u - r - 1), tb_smin(r - rowfloor1, (u - ufloor) >> 1));
             if (PSA_UNLIKELY(dmax < 0)) {
+#ifdef PSA_TB_STATS
+                if (fresh) { if (r - rowfloor1 < 0) ++n_c_row; else if (((u - ufloor) >> 1) < 0) ++n_c_left; else ++n_c_len; }
+#endif
                 if (fresh) break;
                 rlo = 0x7fffffff;       // what this cell needs may have landed since the tile was entered: look again
                 continue;
@@ -379,6 +382,7 @@ __device__ __forceinline__ void t2_walker(const TraceArgs& p, uint8_t* lds) {
         p.state[0] = i; p.state[1] = j; p.state[2] = k; p.state[3] = done; p.state[4] = len; p.state[5] = err;
 #ifdef PSA_TB_STATS
         p.state[6] = ((long long)n_iter << 32) | (unsigned)n_tiles; p.state[7] = ((long long)n_single << 32) | (unsigned)n_miss;
+        p.state[12] = n_c_row; p.state[13] = n_c_left; p.state[14] = n_c_len;
 #endif
         p.state[8] = (long long)__builtin_readcyclecounter() - tc0; p.state[9] = (long long)wall_clock64() - tw0;
     }
