@@ -437,8 +437,8 @@ __device__ __forceinline__ void fill_pk_body(const FillBatch& B) {
     c.carryX = c.carryY = D_up;   // (lane 0's: D of the row above at column 0)
 
     // ---- substitution table rows of this lane in both pairs ----
-    const int symX = row_ok ? (int)qx.a_ids[i - 1] : 0;
-    const int symY = row_ok ? (int)qy.a_ids[i - 1] : 0;
+    const int symX = (row_ok && !(PSA_PK_X & 64)) ? (int)qx.a_ids[i - 1] : 0;   // (64: timing only, every lane on one table row)
+    const int symY = (row_ok && !(PSA_PK_X & 64)) ? (int)qy.a_ids[i - 1] : 0;
     c.trowX = qx.eqtab + (size_t)symX * px.tab_pitch + kTabPad;
     c.trowY = qy.eqtab + (size_t)symY * py.tab_pitch + kTabPad;
     c.msh = 8 * ((64 - lane) & 3);
