@@ -445,6 +445,9 @@ def single_gpu(args):
                                  ("11 = 8 for the recurrence + 3 for the one-byte winner code; SURVEY 8d's 25 priced three "
                                   "compares per aggregate, which this kernel does not do (frac_at_survey_ops keeps that scale)"),
                      "valu_insts_per_cell_executed": pmc_valu_per_cell(kpat, grid * 256, per_launch_pairs * cells1),
+                     "peak_note": ("the peak assumes 2.4 GHz; with its code stores (1 B per cell, 3.9 TB/s) the packed launch runs at "
+                                   "about 1.8 GHz under the device's power management, VALU busy 0.92 of those cycles "
+                                   "(SQ_BUSY_CYCLES over duration in timing-only builds, DESIGN 4.1b)") if packed else None,
                      "kernel_ms": fill_ms, "launches_timed": len(full),
                      "kernel_ms_note": fill_ms_note,
                      "fill_end_ms": [round(t, 3) for t in ends], "fill_start_to_end_ms": [round(f, 3) for f, _ in fills],
