@@ -19,6 +19,12 @@
 // simply ADOPTS the producer's frame of superblock k + 1 at the start of its own superblock k (bases published per
 // superblock beside the ring) and never converts a value.  The first strip of a workgroup picks its own frame (its lane
 // 0's D) and converts at the HBM interface only: granules carry absolute values, 64 columns at a time, one per lane.
+//
+// Memory.  The winner codes leave per block of 16 steps as nontemporal 16-byte stores; the table words are loaded into
+// the registers whose words are dead, two blocks before their first use; the steady loop exists once per input role
+// (row above from LDS / from HBM granules) so that neither carries the other's vector-memory operations, spills nothing
+// and waits on the vector-memory counter with counted waits only; the hand-over between strips is written by lane 63
+// and read by lane 0 alone.  Why each of these: DESIGN 4.1b (the launch runs into the device's power management).
 #pragma once
 #include "psa_fill_v2.hip.h"
 
@@ -30,7 +36,7 @@ constexpr int kPkFrames = 8;    // published frames per ring (a producer is at m
 struct __attribute__((aligned(128))) PkLds {
     int2 ring[kPkNW][kRing];          // ring[w]: input of wave w; slot s = (D of column s-65, V of column s-64), both pairs packed
     int2 stage[kPkNW][kPkStage];      // a wave's last row on its way to HBM granules (same slot numbering)
-    int dummy[kPkNW][320];            // where lanes other than 63 drop their publish writes (16 bytes a lane)
+    int dummy[kPkNW][320];            // where lanes other than 63 drop their publish writes (PSA_PK_MASKED bit 0 off only)
     int dummy2[kPkNW][64];            // where lanes that own no counter drop their counter posts
     int prod[kPkNW];                  // steps completed by the producer of ring[w]
     int cons[kPkNW];                  // ring[w] slots below this number have been read
