@@ -121,8 +121,14 @@ __device__ __forceinline__ bool pk_from_lds(const bool dyn) { return IN == kPkIn
 #ifndef PSA_PK_NOSYNC
 #define PSA_PK_NOSYNC 0
 #endif
+#if PSA_PK_NOSYNC
+#warning "PSA_PK_NOSYNC: timing-only build of fill_strips_pk, its results are WRONG"
+#endif
 #ifndef PSA_PK_X   // further timing-only switches: 1 no publish writes, 2 no ring reads, 4 no code stores, 8 no table loads (the first words stay)
 #define PSA_PK_X 0
+#endif
+#if PSA_PK_X
+#warning "PSA_PK_X: timing-only build of fill_strips_pk, its results are WRONG"
 #endif
 
 // Lane 63's 16 bytes into the next strip's ring.  PSA_PK_MASKED bit 0: under an execution mask of lane 63 alone (two
